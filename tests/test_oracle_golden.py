@@ -1,0 +1,115 @@
+"""Pin the CPU oracle (oracle/shivae_oracle.py) against the golden vectors that were generated
+by importing the reference model (tests/golden/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+
+import _golden
+from oracle import shivae_oracle as so
+
+# fp64 oracle vs the reference's fp32 outputs
+FWD = dict(rtol=2e-5, atol=2e-6)
+GRAD_RTOL = 2e-4  # relative to the largest |grad| entry of the tensor (BPTT over T=100 in fp32)
+
+
+def _run(name, dtype=np.float64):
+    g, cfg, sd = _golden.load(name)
+    m = so.OracleShiVAE(sd, cfg["types_list"], cfg["H"], cfg["Z"], cfg["K"], cfg["learn_std"], dtype=dtype)
+    c = m.forward(g["x"], g["mask"], g["u"], g["eps"], beta=cfg["beta"], temp=cfg["temp"])
+    return g, cfg, sd, m, c
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_forward_matches_reference(name):
+    g, cfg, sd, m, c = _run(name)
+    for ok, gk in (("z", "z"), ("mu", "z_mean"), ("std", "z_std"), ("mu_p", "zp_mean"), ("std_p", "zp_std"),
+                   ("s", "s"), ("probs", "s_probs")):
+        np.testing.assert_allclose(c[ok], g[gk], err_msg=gk, **FWD)
+    gp = _golden.golden_dec_params(g, cfg["types_list"])
+    for i, t in enumerate(cfg["types_list"]):
+        if t["type"] in ("real", "pos"):
+            np.testing.assert_allclose(c["dec_params"][i][0], gp[i][0], **FWD)
+            np.testing.assert_allclose(c["dec_params"][i][1], gp[i][1], **FWD)
+        else:
+            np.testing.assert_allclose(c["dec_params"][i], gp[i], rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(c["nll_attr"][i], g["nll_attr/%d" % i], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_loss_terms_match_reference(name):
+    g, cfg, sd, m, c = _run(name)
+    for ty in ("real", "pos", "bin", "cat"):
+        np.testing.assert_allclose(c["nll_type_b"][ty], g["nll_b/nll_" + ty], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(c["klz_b"], g["klz_b"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c["kls_b"], g["kls_b"], rtol=1e-4, atol=1e-5)
+    for k, v in c["losses"].items():
+        np.testing.assert_allclose(v, g["loss/" + k], rtol=1e-5, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_gradients_match_reference(name):
+    g, cfg, sd, m, c = _run(name)
+    G = m.backward()
+    assert set(G) == set(sd)
+    for k in sd:
+        ref = g["grad/" + k]
+        scale = max(np.abs(ref).max(), 1e-3)
+        err = np.abs(G[k] - ref).max() / scale
+        assert err < GRAD_RTOL, (k, err)
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_clip_adam_matches_reference(name):
+    g, cfg, sd, m, c = _run(name)
+    G = m.backward()
+    P = {k: v.astype(np.float64) for k, v in sd.items()}
+    mm = {k: np.zeros_like(v) for k, v in P.items()}
+    vv = {k: np.zeros_like(v) for k, v in P.items()}
+    tot = so.clip_adam_step(P, G, mm, vv, step=1, lr=5e-3, clip=0.5)
+    np.testing.assert_allclose(tot, g["grad_norm"], rtol=1e-4)
+    for k in sd:
+        # first Adam step moves each weight by ~lr*sign(g): compare the update, not the weight
+        # (the step-1 update lr*g/(|g|+1e-8) is ill-conditioned where |g| ~ 1e-8: loose bound there)
+        gc = np.abs(G[k]) * min(0.5 / (tot + 1e-6), 1.0)
+        atol = np.where(gc > 1e-5, 2e-4 * 5e-3 + 1e-7, 5e-4)
+        assert (np.abs((P[k] - sd[k]) - (g["adam1/" + k] - sd[k])) <= atol).all(), k
+
+
+@pytest.mark.parametrize("name", ["cfg1_T100_B8", "tiny_all"])
+def test_reconstruction_params_match_reference(name):
+    g, cfg, sd = _golden.load(name)
+    m = so.OracleShiVAE(sd, cfg["types_list"], cfg["H"], cfg["Z"], cfg["K"], cfg["learn_std"])
+    dp, _ = m.reconstruction_params(g["x"], g["u"], g["eps"], temp=0.01)
+    gp = _golden.golden_dec_params(g, cfg["types_list"], prefix="rec")
+    for i, t in enumerate(cfg["types_list"]):
+        a = dp[i][0] if t["type"] in ("real", "pos") else dp[i]
+        b = gp[i][0] if t["type"] in ("real", "pos") else gp[i]
+        np.testing.assert_allclose(a, b, rtol=5e-4, atol=5e-5)
+
+
+def test_oracle_fp32_close_to_fp64():
+    g, cfg, sd, m64, c64 = _run("tiny_all")
+    _, _, _, m32, c32 = _run("tiny_all", dtype=np.float32)
+    np.testing.assert_allclose(c32["losses"]["n_elbo"], c64["losses"]["n_elbo"], rtol=1e-5)
+    G64, G32 = m64.backward(), m32.backward()
+    for k in G64:
+        scale = max(np.abs(G64[k]).max(), 1e-3)
+        assert np.abs(G32[k] - G64[k]).max() / scale < 1e-4, k
+
+
+def test_oracle_numerical_gradient():
+    """Finite-difference check of the hand-derived backward on a few scalars (fp64)."""
+    g, cfg, sd, m, c = _run("tiny_miss90")
+    G = m.backward()
+    rng = np.random.default_rng(0)
+    for k in ["rnn.weight_hh_l0", "encoder.phi_x_s.0.weight", "encoder.enc.0.weight", "phi_z.0.bias",
+              "prior.0.weight", "dec.decoder_dict.var3.dec_p_cat.2.weight", "encoder.phi_x.0.weight"]:
+        idx = tuple(rng.integers(0, s) for s in sd[k].shape)
+        h = 1e-6
+        vals = []
+        for sgn in (+1, -1):
+            P = {kk: vv.astype(np.float64).copy() for kk, vv in sd.items()}
+            P[k][idx] += sgn * h
+            mm = so.OracleShiVAE(P, cfg["types_list"], cfg["H"], cfg["Z"], cfg["K"], cfg["learn_std"])
+            vals.append(mm.forward(g["x"], g["mask"], g["u"], g["eps"], cfg["beta"], cfg["temp"])["losses"]["n_elbo"])
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - G[k][idx]) < 1e-5 * max(1.0, abs(fd)), (k, idx, fd, G[k][idx])
