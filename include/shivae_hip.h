@@ -1,0 +1,186 @@
+/* shivae_hip.h -- C ABI of libshivae_hip.so: the Shi-VAE train step (ELBO forward + backward) as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (dbarrejon/Shi-VAE) has no FFI / plugin interface: its hot path is the Python
+ * nn.Module API driven by Trainer.train_epoch (src/models/trainers.py:197-226).  This library sits
+ * BELOW that API; each entry point cites the reference code it replaces.  The Python host layer in
+ * shi-vae_amd/ (ShiVAE / Trainer with the reference's signatures) binds these with ctypes.
+ *
+ * Conventions
+ *  - every pointer named *_dev / documented "device" is a HIP device pointer owned by the CALLER
+ *    (torch allocates); the library allocates only small plan-time tables (freed in plan_destroy);
+ *  - all arithmetic is fp32; masks are uint8 (1 = missing), as torch.bool in the reference;
+ *  - tensors are time-major and contiguous: x[T][B][X], mask[T][B][X], u[T][B][K], eps[T][B][Z];
+ *  - every call enqueues on the given hipStream_t and does not synchronise; one host thread per GPU;
+ *  - return value: 0 = ok, <0 = error, text via shivae_last_error() (thread-local).
+ */
+#ifndef SHIVAE_HIP_H
+#define SHIVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHIVAE_OK 0
+#define SHIVAE_ERR_INVALID (-1)
+#define SHIVAE_ERR_HIP (-2)
+#define SHIVAE_ERR_UNBOUND (-3)
+
+typedef struct shivae_plan shivae_plan;
+typedef void* shivae_stream; /* hipStream_t */
+
+/* attribute types, lib/utils.py:200-212 / data_types.csv "type" column */
+enum { SHIVAE_REAL = 0, SHIVAE_POS = 1, SHIVAE_BIN = 2, SHIVAE_CAT = 3 };
+
+/* Model + sizing description.  Mirrors ShiVAE.__init__(h_dim, z_dim, s_dim, n_layers=1, types_list,
+ * learn_std) (src/models/shivae.py:25-70). */
+typedef struct {
+    int T;               /* time steps per call (exact) */
+    int B;               /* sequences per call (exact; callers split larger batches) */
+    int H, Z, K;         /* h_dim, z_dim, s_dim */
+    int n_attr;          /* len(types_list) */
+    const int* attr_type;   /* [n_attr] SHIVAE_REAL.. */
+    const int* attr_nclass; /* [n_attr] one-hot width for SHIVAE_CAT (>=2), ignored otherwise */
+    int learn_std;       /* decoders.py:71-86 */
+    int chunk_rows;      /* rows (t,b pairs) of decoder activations kept at once; 0 = auto */
+} shivae_config;
+
+/* parameter tensors of the flat fp32 parameter buffer (state_dict key in the comment) */
+enum {
+    SHIVAE_P_PHIX0_W = 0, SHIVAE_P_PHIX0_B, /* encoder.phi_x.0   [H,X]      encoders.py:47-48 */
+    SHIVAE_P_PHIX2_W, SHIVAE_P_PHIX2_B,     /* encoder.phi_x.2   [H,H]      encoders.py:50 */
+    SHIVAE_P_XS0_W, SHIVAE_P_XS0_B,         /* encoder.phi_x_s.0 [H,X+H]    encoders.py:54 */
+    SHIVAE_P_XS2_W, SHIVAE_P_XS2_B,         /* encoder.phi_x_s.2 [K,H]      encoders.py:56 */
+    SHIVAE_P_E0_W, SHIVAE_P_E0_B,           /* encoder.enc.0     [H,2H+K]   encoders.py:61 */
+    SHIVAE_P_E2_W, SHIVAE_P_E2_B,           /* encoder.enc.2     [H,H]      encoders.py:63 */
+    SHIVAE_P_ENCMEAN_W, SHIVAE_P_ENCMEAN_B, /* encoder.enc_mean  [Z,H]      encoders.py:65 */
+    SHIVAE_P_ENCSTD_W, SHIVAE_P_ENCSTD_B,   /* encoder.enc_std.0 [Z,H]      encoders.py:67 */
+    SHIVAE_P_PHIZ_W, SHIVAE_P_PHIZ_B,       /* phi_z.0           [H,Z]      shivae.py:52 */
+    SHIVAE_P_PRIOR0_W, SHIVAE_P_PRIOR0_B,   /* prior.0           [H,H+K]    shivae.py:57 */
+    SHIVAE_P_PRIORMEAN_W, SHIVAE_P_PRIORMEAN_B, /* prior_mean    [Z,H]      shivae.py:59 */
+    SHIVAE_P_PRIORSTD_W, SHIVAE_P_PRIORSTD_B,   /* prior_std.0   [Z,H]      shivae.py:60 */
+    SHIVAE_P_RNN_WIH, SHIVAE_P_RNN_WHH,     /* rnn.weight_{ih,hh}_l0 [4H,H] shivae.py:68 */
+    SHIVAE_P_RNN_BIH, SHIVAE_P_RNN_BHH,     /* rnn.bias_{ih,hh}_l0   [4H] */
+    /* per attribute (attr = index into types_list), decoders.py:60-66 */
+    SHIVAE_P_DEC0_W, SHIVAE_P_DEC0_B,       /* dec.decoder_dict.<v>.dec.0 [2H,2H+K] */
+    SHIVAE_P_DEC2_W, SHIVAE_P_DEC2_B,       /* ...dec.2 [H,2H] */
+    SHIVAE_P_DEC4_W, SHIVAE_P_DEC4_B,       /* ...dec.4 [H,H] */
+    SHIVAE_P_HEAD0_W, SHIVAE_P_HEAD0_B,     /* bin: dec_p.0 / cat: dec_p_cat.0 [H,H]  decoders.py:89-102 */
+    SHIVAE_P_HEADMEAN_W, SHIVAE_P_HEADMEAN_B, /* real/pos: dec_mean [1,H]             decoders.py:70,79 */
+    SHIVAE_P_HEADSTD_W, SHIVAE_P_HEADSTD_B,   /* real/pos, learn_std: dec_std.0 [1,H] decoders.py:72,82 */
+    SHIVAE_P_HEADOUT_W, SHIVAE_P_HEADOUT_B, /* bin: dec_p.2 [1,H] / cat: dec_p_cat.2 [C-1,H] */
+    SHIVAE_P_COUNT
+};
+
+/* named per-(t,b) outputs of the last shivae_elbo_step, copied out UNPADDED as [T][B][width] */
+enum {
+    SHIVAE_O_Z = 0,      /* z_t sample        [Z]  (shivae.py:146 z_tup[0]) */
+    SHIVAE_O_Z_MEAN,     /*                   [Z]  z_tup[1] */
+    SHIVAE_O_Z_STD,      /*                   [Z]  z_tup[2] */
+    SHIVAE_O_ZP_MEAN,    /* prior mean        [Z]  z_prior_tup[0] */
+    SHIVAE_O_ZP_STD,     /* prior std         [Z]  z_prior_tup[1] */
+    SHIVAE_O_S,          /* s_t (soft sample) [K]  s_tup[0] */
+    SHIVAE_O_S_PROBS,    /*                   [K]  s_tup[1] */
+    SHIVAE_O_DEC_PARAMS, /* raw decoder head outputs [P] (needs SHIVAE_STEP_KEEP_PARAMS); layout per
+                            attribute in types_list order: real/pos -> mean[, pre-softplus std if
+                            learn_std]; bin -> logit; cat -> theta_1..theta_{C-1} (theta_0 == 0) */
+    SHIVAE_O_ROWLOSS,    /* per-timestep ELBO terms [6]: nll_real,nll_pos,nll_bin,nll_cat,kl_z,kl_s */
+    SHIVAE_O_H_PREV,     /* h_{t-1}           [H] */
+    SHIVAE_O_PHI_Z,      /*                   [H] */
+    SHIVAE_O_COUNT
+};
+
+#define SHIVAE_STEP_FORWARD_ONLY 1 /* no gradients (validation / imputation) */
+#define SHIVAE_STEP_KEEP_PARAMS 2  /* keep all decoder parameters for SHIVAE_O_DEC_PARAMS */
+
+const char* shivae_last_error(void);
+/* build id string, e.g. "shivae_hip gfx950 <date>" */
+const char* shivae_version(void);
+
+/* ---- plan: model description, parameter layout, workspace ---------------------------------- */
+/* replaces ShiVAE.__init__ bookkeeping (shivae.py:25-70, utils.py:229-241,291-315) */
+int shivae_plan_create(const shivae_config* cfg, shivae_plan** out);
+void shivae_plan_destroy(shivae_plan* plan);
+
+/* total floats of the flat parameter (and gradient) buffer */
+int64_t shivae_plan_num_params(const shivae_plan* plan);
+/* float offset / shape of one parameter tensor inside the flat buffer; attr is ignored for the
+ * non-decoder tensors.  Returns SHIVAE_ERR_INVALID if the tensor does not exist for that attribute. */
+int shivae_plan_param_info(const shivae_plan* plan, int tensor_id, int attr, int64_t* offset, int* rows,
+                           int* cols);
+/* x_dim (sum of dims, utils.py:229-241) and P (decoder parameter columns per row) */
+int shivae_plan_x_dim(const shivae_plan* plan);
+int shivae_plan_p_dim(const shivae_plan* plan);
+int shivae_plan_chunk_rows(const shivae_plan* plan);
+
+size_t shivae_plan_workspace_bytes(const shivae_plan* plan);
+/* attach caller-owned device memory: workspace (>= workspace_bytes, 256-B aligned; it is zeroed
+ * here, synchronously), the flat parameter buffer and the flat gradient buffer */
+int shivae_plan_bind(shivae_plan* plan, void* workspace_dev, size_t workspace_bytes, float* params_dev,
+                     float* grads_dev);
+
+/* ---- the step ------------------------------------------------------------------------------ */
+/* replaces model(x, mask, beta, temp) + n_elbo.backward() (trainers.py:212-215,
+ * base_missvae.py:144-231, shivae.py:72-154) for one contiguous batch of exactly cfg.B sequences.
+ *   u, eps    : explicit noise (what samplers.py:25 torch.rand and :60 normal_() would draw)
+ *   inv_batch : 1/B_total -- the batch mean of base_missvae.py:212; with micro-batches or data
+ *               parallelism pass the GLOBAL batch so that gradients add up across calls/ranks
+ *   losses_dev: 9 floats, ACCUMULATED (+=): n_elbo, nll_loss, kld, kld_q_z, kld_q_s, nll_real,
+ *               nll_pos, nll_bin, nll_cat (base_missvae.py:215-230); caller zeroes them
+ * Gradients are ACCUMULATED into the bound gradient buffer (zero it with shivae_zero). */
+int shivae_elbo_step(shivae_plan* plan, const float* x_dev, const uint8_t* mask_dev, const float* u_dev,
+                     const float* eps_dev, float beta, float temp, float inv_batch, int flags,
+                     float* losses_dev, shivae_stream stream);
+
+/* copy one named output of the last step into dst_dev as [T][B][width] (unpadded) */
+int shivae_get_output(shivae_plan* plan, int which, float* dst_dev, shivae_stream stream);
+int shivae_output_width(const shivae_plan* plan, int which);
+/* per-sequence sums over time of the last step: [B][6] (order as SHIVAE_O_ROWLOSS) */
+int shivae_get_persum(shivae_plan* plan, float* dst_dev, shivae_stream stream);
+
+/* ---- individual kernels (exported for parity tests and for callers that compose their own step) */
+/* base_missvae.py:233-285 heter_nll (eval_obs=False) forward, fused with d nll/d params.
+ * params: raw head outputs [rows][ldp] in the SHIVAE_O_DEC_PARAMS layout; dparams may be NULL
+ * (forward only) or alias params; rowloss: [rows][6], columns 0..3 written. */
+int shivae_heter_nll(shivae_plan* plan, const float* x_dev, const uint8_t* mask_dev, const float* params_dev,
+                     int ldp, float* dparams_dev, int rows, float grad_scale, float* rowloss_dev,
+                     shivae_stream stream);
+/* base_missvae.py:287-343 kl_q_z + kl_q_s forward (rowloss columns 4,5), fused with their gradients
+ * scaled by kl_scale (= beta*grad_scale): d/dmu_q, d/dstd_q, d/dmu_p, d/d(pre-softplus std_p) and
+ * d/d(s logits) through s_probs = softmax(logits).  Gradient pointers may all be NULL. */
+int shivae_kl_terms(const float* mu_q, const float* std_q, const float* mu_p, const float* std_p, int ldz,
+                    const float* s_probs, int ldk, int rows, int Z, int K, float kl_scale, float* dmu_q,
+                    float* dstd_q, float* dmu_p, float* dstd_p_pre, float* dlogits, float* rowloss_dev,
+                    shivae_stream stream);
+/* samplers.py:23-62: s_probs = softmax(logits), s = softmax((logits+gumbel(u))/temp), z = eps*std+mean */
+int shivae_reparam_fwd(const float* logits, const float* u, int ldk, int K, float temp, float* s, float* s_probs,
+                       const float* mean, const float* std, const float* eps, int ldz, int Z, float* z, int rows,
+                       shivae_stream stream);
+int shivae_reparam_bwd(const float* s, const float* ds, int ldk, int K, float temp, float* dlogits,
+                       const float* eps, const float* dz, int ldz, int Z, float* dmean, float* dstd, int rows,
+                       shivae_stream stream);
+/* C = epilogue(op(A) op(B)) on the fp32 matrix cores; layout 0: A[M,K] B[N,K]^T (nn.Linear forward),
+ * 1: A[M,K] B[K,N] (input gradient), 2: A[K,M]^T B[K,N] (weight gradient).  epi bits: 1 bias,
+ * 2 relu, 4 softplus, 8 += C, 16 gate by aux>0, 32 atomic accumulate (alone; required if splitk>1) */
+int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                int ldc, const float* bias, const float* aux, int ldaux, int epi, int splitk,
+                shivae_stream stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------ */
+int shivae_zero(float* buf_dev, int64_t n, shivae_stream stream);
+/* sum of squares of a flat buffer -> *out_dev (overwritten); scratch_dev: >= 1024 floats */
+int shivae_sqnorm(const float* buf_dev, int64_t n, float* scratch_dev, float* out_dev, shivae_stream stream);
+/* torch.nn.utils.clip_grad_norm_(params, clip) followed by torch.optim.Adam.step()
+ * (trainers.py:222-224) on flat buffers; sqnorm_dev holds the squared global gradient norm
+ * (after any all-reduce).  step is the 1-based Adam step count. */
+int shivae_clip_adam(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                     int64_t n, const float* sqnorm_dev, float clip, float lr, float beta1, float beta2,
+                     float eps, int step, shivae_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHIVAE_HIP_H */

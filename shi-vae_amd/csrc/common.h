@@ -1,0 +1,161 @@
+// Shared declarations for the Shi-VAE HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/shivae_hip.h"
+
+namespace shivae {
+
+void set_error(const char* fmt, ...);
+
+#define SV_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            shivae::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,              \
+                              hipGetErrorString(e__));                                  \
+            return SHIVAE_ERR_HIP;                                                      \
+        }                                                                               \
+    } while (0)
+
+#define SV_REQUIRE(cond, ...)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            shivae::set_error(__VA_ARGS__);                                             \
+            return SHIVAE_ERR_INVALID;                                                  \
+        }                                                                               \
+    } while (0)
+
+#define SV_TRY(expr)                                                                    \
+    do {                                                                                \
+        int r__ = (expr);                                                               \
+        if (r__ != SHIVAE_OK) return r__;                                               \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// One problem of a grouped GEMM: all groups share M,N,K and leading dimensions.
+struct GemmGroup {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;  // [N] or null
+    const float* aux;   // [M,N] activation whose sign gates the output (ReLU backward) or null
+};
+
+enum GemmLayout {
+    // C[M,N] = A[M,K] * B[N,K]^T   (forward linear: activations x weight[out,in])
+    GEMM_NT = 0,
+    // C[M,N] = A[M,K] * B[K,N]     (input gradient: dY x weight[out,in])
+    GEMM_NN = 1,
+    // C[M,N] = A[K,M]^T * B[K,N]   (weight gradient: dY^T x activations, K = rows)
+    GEMM_TN = 2,
+};
+
+enum GemmEpi {
+    EPI_BIAS = 1,      // + bias[n]
+    EPI_RELU = 2,      // max(v,0)
+    EPI_SOFTPLUS = 4,  // softplus, threshold 20
+    EPI_ADDC = 8,      // + C_old (before the activation)
+    EPI_MASK = 16,     // * (aux[m,n] > 0)   (after everything else)
+    EPI_ATOMIC = 32,   // atomicAdd into C (split-K / cross-launch accumulation); excludes the others
+};
+
+struct GemmDesc {
+    int layout;
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int epi;
+    int splitk;     // >=1; >1 requires EPI_ATOMIC
+    int unaligned;  // 1: some group base pointer is not 16-B aligned -> scalar global loads
+};
+
+// groups_dev: device array of ngroups GemmGroup, or nullptr with ngroups==1 and g0 used.
+int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                hipStream_t stream);
+
+// bias gradient: out[g][n] += sum_m Y_g[m*ld + n]
+struct ColsumGroup {
+    const float* Y;
+    float* out;
+};
+int launch_colsum(int M, int N, int ld, const ColsumGroup* groups_dev, int ngroups,
+                  const ColsumGroup& g0, hipStream_t stream);
+
+
+// ---------------------------------------------------------------- loss kernels (loss.hip)
+// One attribute of types_list: where it lives in x (one-hot expanded, utils.py:291-315) and in the
+// decoder-parameter row.
+struct AttrDesc {
+    int type;  // SHIVAE_REAL..SHIVAE_CAT
+    int xoff;  // first x column
+    int dim;   // x columns (1, or C for cat)
+    int poff;  // first parameter column
+    int nout;  // parameter columns: real/pos 1 (+1 if learn_std), bin 1, cat C-1
+};
+
+int launch_heter_nll(const AttrDesc* attrs_dev, int D, int learn_std, const float* x, int ldx,
+                     const uint8_t* mask, int ldm, const float* P, int ldp, float* dP, int ldd, int rows,
+                     float gs, float* rowloss, hipStream_t stream);
+int launch_kl(const float* mu, const float* sd, const float* mup, const float* sdp, int ldz,
+              const float* probs, int ldk, float* dmu, float* dsd, float* dmup, float* dsdp_pre, float* dlg,
+              int rows, int Z, int K, float kz, float* rowloss, hipStream_t stream);
+int launch_loss_reduce(const float* rowloss, float* persum, int T, int B, float beta, float inv_batch,
+                       float* losses, hipStream_t stream);
+int launch_reparam_fwd(const float* logits, const float* u, int ldk, int K, float temp, float* s, float* probs,
+                       const float* mean, const float* sd, const float* eps, int ldz, int Z, float* z, int rows,
+                       hipStream_t stream);
+int launch_reparam_bwd(const float* s, const float* ds, int ldk, int K, float temp, float* dlogits,
+                       const float* eps, const float* dz, int ldz, int Z, float* dmean, float* dsd, int rows,
+                       hipStream_t stream);
+
+// ---------------------------------------------------------------- recurrent scan (scan.hip)
+// float offsets into the packed-weight buffer; t_* are the transposed images used by the backward
+struct ScanWOff {
+    int xsh, lg, b_lg, e0s, e0h, e2, b_e2, mu, b_mu, sd, b_sd, pz, b_pz, ih, hh, b_g;
+    int t_ih, t_hh, t_pz, t_mu, t_sd, t_e2, t_e0s, t_e0h, t_lg, t_xsh;
+};
+
+// Row-major record buffers, row = t*B + b, leading dims padded: Hp/Zp/Kp (multiples of 16),
+// emb = [phi_z (Hp) | s (Kp) | h_prev (Hp)] with Ep = 2*Hp + Kp.  u/eps are the caller's unpadded
+// [T][B][K] / [T][B][Z].
+struct ScanArgs {
+    int T, B, H, Z, K, Hp, Zp, Kp, Ep;
+    float temp;
+    const float* wpack;
+    ScanWOff w;
+    const float *xs_pre, *ex_pre, *u, *eps;
+    float *emb, *as_, *e1, *e2, *logits, *probs, *mu, *sd, *z, *gates, *cnew, *h_last;
+    const float *d_emb, *dmu_ext, *dsd_ext, *dlg_kl;
+    float *d_gates, *d_phiz_pre, *d_mu, *d_sd_pre, *d_e2_pre, *d_e1_pre, *d_lg_pre, *d_as_pre;
+};
+
+// dst[packed] = W (or W^T) zero-padded; blocks model the 4 LSTM gates (i,f,g,o each padded H->Hp)
+struct PackJob {
+    const float* src;
+    const float* src2;  // bias jobs: optional second addend (b_ih + b_hh)
+    int ld, transposed;
+    int Op, Ip;                // padded out / in extents (multiples of 16)
+    int oblk_true, oblk_pad;   // out index o -> block o/oblk_pad, valid if o%oblk_pad < oblk_true
+    int iblk_true, iblk_pad;
+    int dst_off;
+};
+
+int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int nb, float* dst, hipStream_t stream);
+int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream);
+
+// ---------------------------------------------------------------- misc (optim.hip)
+int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, float* embc, int ldc, int rows,
+                       hipStream_t stream);
+int launch_expand_add_emb(const float* dembc, int ldc, int H, int K, float* d_emb, int Ep, int Hp, int Kp, int rows,
+                          hipStream_t stream);
+int launch_unpad_copy(const float* src, int ld, int col0, int width, float* dst, int64_t rows, hipStream_t stream);
+int launch_sqnorm(const float* buf, int64_t n, float* scratch, float* out, hipStream_t stream);
+int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm, float clip,
+                     float lr, float b1, float b2, float eps, int step, hipStream_t stream);
+
+}  // namespace shivae

@@ -1,0 +1,281 @@
+// Grouped fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf chain).
+//
+// This is the workhorse of the Shi-VAE step: every Linear of the reference that is NOT on the
+// serial recurrence (encoders.py:47-51 phi_x; shivae.py:56-61 prior; decoders.py:60-102 the
+// per-attribute decoder trunks and heads = 99 % of the FLOPs) and all of their backward passes
+// (input gradients and weight gradients) are batched over the T*B rows and run through here.
+//
+// Tile: (WM*TM*32) x (WN*TN*32) x 32 per workgroup of WM*WN waves (64 lanes each); each wave owns
+// TM x TN accumulators of 32x32.  Operands are staged global -> registers -> LDS with the next
+// K-tile's global loads in flight during the MFMAs of the current one.
+//
+// LDS images and bank behaviour (MI355X_MICROARCH.md, LDS):
+//   K-contiguous operand  : [rows][32+4] floats.  A lane reads the 4 consecutive k it needs for
+//                           four MFMAs with one ds_read_b128; row stride 36 dwords puts the 16
+//                           lanes of a b128 lane group on 16 distinct 4-bank slots (conflict-free).
+//   row-contiguous operand: [32][rows] floats.  Lanes 0..31 read consecutive floats (ds_read_b32,
+//                           conflict-free).
+// MFMA operand map (cdna_hip_programming.md s.3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; with per-lane float4 v = X[.][8s+4h .. 8s+4h+3] (h = l>>5), MFMA number c uses
+// v[c] on both sides, i.e. the k pair {8s+c, 8s+4+c}.  D: col = l&31, row = (r&3)+8*(r>>2)+4*h.
+#include <algorithm>
+
+#include "common.h"
+
+namespace shivae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+template <bool KC, int ROWS, int NT>
+struct TileLoader {
+    // KC : global X[row*ld + k], tile rows = ROWS along the M/N extent, 32 along K
+    // !KC: global X[k*ld + row]
+    static constexpr int NV = ROWS * 8 / NT;  // float4 per thread
+    float4 v[NV > 0 ? NV : 1];
+
+    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int row0, int nrows, int k0,
+                                         int kend, bool vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * NT;
+            int r, k;
+            if (KC) { r = f >> 3; k = (f & 7) * 4; }
+            else    { k = f / (ROWS / 4); r = (f % (ROWS / 4)) * 4; }
+            const int gr = row0 + r, gk = k0 + k;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                if (gr < nrows) {
+                    const float* p = X + (size_t)gr * ld + gk;
+                    if (vec && gk + 3 < kend) x = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gk + 0 < kend) x.x = p[0];
+                        if (gk + 1 < kend) x.y = p[1];
+                        if (gk + 2 < kend) x.z = p[2];
+                        if (gk + 3 < kend) x.w = p[3];
+                    }
+                }
+            } else {
+                if (gk < kend) {
+                    const float* p = X + (size_t)gk * ld + gr;
+                    if (vec && gr + 3 < nrows) x = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gr + 0 < nrows) x.x = p[0];
+                        if (gr + 1 < nrows) x.y = p[1];
+                        if (gr + 2 < nrows) x.z = p[2];
+                        if (gr + 3 < nrows) x.w = p[3];
+                    }
+                }
+            }
+            v[i] = x;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * NT;
+            int off;
+            if (KC) off = (f >> 3) * 36 + (f & 7) * 4;
+            else    off = (f / (ROWS / 4)) * ROWS + (f % (ROWS / 4)) * 4;
+            *reinterpret_cast<float4*>(lds + off) = v[i];
+        }
+    }
+};
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ float4 read_frag(const float* lds, int row, int s, int h) {
+    if (KC) return *reinterpret_cast<const float4*>(lds + row * 36 + s * 8 + h * 4);
+    const float* p = lds + (s * 8 + h * 4) * ROWS + row;
+    return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
+}
+
+struct GemmParams {
+    int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB;
+    const GemmGroup* groups;
+    GemmGroup g0;
+};
+
+template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    constexpr int LDS_A = A_KC ? BM * 36 : 32 * BM;
+    constexpr int LDS_B = B_KC ? BN * 36 : 32 * BN;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_A + LDS_B];
+    float* ldsA = lds;
+    float* ldsB = lds + LDS_A;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int gidx = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+    const GemmGroup g = p.groups ? p.groups[gidx] : p.g0;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = ks * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    TileLoader<A_KC, BM, NT> la;
+    TileLoader<B_KC, BN, NT> lb;
+    if (kbeg < kend) {
+        la.load(g.A, p.lda, m0, p.M, kbeg, kend, p.vecA, tid);
+        lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, p.vecB, tid);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        la.store(ldsA, tid);
+        lb.store(ldsB, tid);
+        __syncthreads();
+        if (k0 + 32 < kend) {
+            la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, p.vecA, tid);
+            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, p.vecB, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int x = 0; x < TM; ++x) a[x] = read_frag<A_KC, BM>(ldsA, (wm * TM + x) * 32 + li, s, lh);
+#pragma unroll
+            for (int y = 0; y < TN; ++y) b[y] = read_frag<B_KC, BN>(ldsB, (wn * TN + y) * 32 + li, s, lh);
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].y, acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].z, b[y].z, acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].w, b[y].w, acc[x][y], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lanes 0..31 of a half hold 32 consecutive columns of one row -> 128-B row segments
+    const int epi = p.epi;
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int col = n0 + (wn * TN + y) * 32 + li;
+            if (col >= p.N) continue;
+            const float bias = (epi & EPI_BIAS) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float* cp = g.C + (size_t)row * p.ldc + col;
+                float v = acc[x][y][r];
+                if (epi & EPI_ATOMIC) {
+                    atomicAdd(cp, v);
+                    continue;
+                }
+                v += bias;
+                if (epi & EPI_ADDC) v += *cp;
+                if (epi & EPI_RELU) v = fmaxf(v, 0.f);
+                if (epi & EPI_SOFTPLUS) v = softplus_f(v);
+                if (epi & EPI_MASK) v = g.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+                *cp = v;
+            }
+        }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
+    SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
+               ngroups, p.splitk);
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_layout(const GemmParams& p, int ngroups, hipStream_t stream) {
+    // tile choice: 128x128 by default; skinny shapes get a 32-wide tile on the skinny side
+    if (p.N <= 32) return launch_cfg<A_KC, B_KC, 4, 1, 2, 1>(p, ngroups, stream);   // 256 x 32
+    if (p.M <= 32) return launch_cfg<A_KC, B_KC, 1, 4, 1, 2>(p, ngroups, stream);   // 32 x 256
+    if (p.N <= 64) return launch_cfg<A_KC, B_KC, 4, 1, 2, 2>(p, ngroups, stream);   // 256 x 64
+    if (p.M <= 64) return launch_cfg<A_KC, B_KC, 1, 4, 2, 2>(p, ngroups, stream);   // 64 x 256
+    return launch_cfg<A_KC, B_KC, 2, 2, 2, 2>(p, ngroups, stream);                  // 128 x 128
+}
+
+int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                hipStream_t stream) {
+    if (d.M <= 0 || d.N <= 0 || ngroups <= 0) return SHIVAE_OK;
+    SV_REQUIRE(d.K >= 0 && d.splitk >= 1, "gemm: bad K/splitk");
+    SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "gemm: %d groups need a device group table", ngroups);
+    SV_REQUIRE(d.splitk == 1 || (d.epi == EPI_ATOMIC), "gemm: split-K needs the atomic epilogue");
+    SV_REQUIRE(!(d.epi & EPI_ATOMIC) || d.epi == EPI_ATOMIC, "gemm: atomic epilogue excludes the others");
+    GemmParams p;
+    p.M = d.M; p.N = d.N; p.K = d.K;
+    p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux;
+    p.epi = d.epi; p.splitk = d.splitk;
+    p.kchunk = round_up(ceil_div(d.K > 0 ? d.K : 1, d.splitk), 32);
+    p.groups = groups_dev; p.g0 = g0;
+    const bool a_kc = d.layout != GEMM_TN, b_kc = d.layout == GEMM_NT;
+    // vector (16-B) global loads need aligned bases/strides and a contiguous extent that is a
+    // multiple of 4; group tables are built by the plan, which only marks them vectorisable when
+    // every group base is 16-B aligned (checked here for the inline group only).
+    const int extA = a_kc ? d.K : d.M, extB = b_kc ? d.K : d.N;
+    p.vecA = (d.lda % 4 == 0) && (extA % 4 == 0) && (groups_dev || aligned16(g0.A));
+    p.vecB = (d.ldb % 4 == 0) && (extB % 4 == 0) && (groups_dev || aligned16(g0.B));
+    if (d.unaligned) p.vecA = p.vecB = 0;
+    switch (d.layout) {
+        case GEMM_NT: return launch_layout<true, true>(p, ngroups, stream);
+        case GEMM_NN: return launch_layout<true, false>(p, ngroups, stream);
+        case GEMM_TN: return launch_layout<false, false>(p, ngroups, stream);
+    }
+    set_error("gemm: unknown layout %d", d.layout);
+    return SHIVAE_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+struct ColsumParams {
+    int M, N, ld, rows_per_block;
+    const ColsumGroup* groups;
+    ColsumGroup g0;
+};
+
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumParams p) {
+    __shared__ float part[4][64];
+    const ColsumGroup g = p.groups ? p.groups[blockIdx.y] : p.g0;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+    const int r0 = blockIdx.z * p.rows_per_block, r1 = min(p.M, r0 + p.rows_per_block);
+    float s = 0.f;
+    if (c < p.N)
+        for (int r = r0 + ry; r < r1; r += 4) s += g.Y[(size_t)r * p.ld + c];
+    part[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < p.N) atomicAdd(g.out + c, part[0][threadIdx.x] + part[1][threadIdx.x] +
+                                                     part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+int launch_colsum(int M, int N, int ld, const ColsumGroup* groups_dev, int ngroups, const ColsumGroup& g0,
+                  hipStream_t stream) {
+    if (M <= 0 || N <= 0 || ngroups <= 0) return SHIVAE_OK;
+    SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "colsum: groups need a device table");
+    ColsumParams p;
+    p.M = M; p.N = N; p.ld = ld;
+    // enough blocks to fill the chip, at least 256 rows each
+    int zs = ceil_div(2048, ceil_div(N, 64) * ngroups);
+    zs = std::max(1, std::min(zs, ceil_div(M, 256)));
+    p.rows_per_block = ceil_div(M, zs);
+    zs = ceil_div(M, p.rows_per_block);
+    p.groups = groups_dev; p.g0 = g0;
+    SV_REQUIRE(ngroups <= 65535 && zs <= 65535, "colsum grid too large");
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), ngroups, zs), dim3(256), 0, stream, p);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+}  // namespace shivae

@@ -1,0 +1,140 @@
+// Small streaming kernels around the step: layout shuffles between the padded scan records and the
+// compact decoder input, the global gradient norm and the fused clip + Adam update
+// (trainers.py:222-224: clip_grad_norm_(params, clip) then optimizer.step()).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace shivae {
+
+// embc[r][0:H | H:H+K | H+K:E] = emb[r][0:H | Hp:Hp+K | Hp+Kp:Hp+Kp+H]   (decoders.py:127 cat order)
+__global__ void compact_emb_kernel(const float* __restrict__ emb, int Ep, int Hp, int Kp, int H, int K,
+                                   float* __restrict__ embc, int ldc, int rows) {
+    const int E = 2 * H + K;
+    const size_t n = (size_t)rows * E;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / E;
+        const int c = (int)(i % E);
+        const int sc = c < H ? c : (c < H + K ? Hp + (c - H) : Hp + Kp + (c - H - K));
+        embc[r * ldc + c] = emb[r * Ep + sc];
+    }
+}
+
+__global__ void expand_add_emb_kernel(const float* __restrict__ dembc, int ldc, int H, int K,
+                                      float* __restrict__ d_emb, int Ep, int Hp, int Kp, int rows) {
+    const int E = 2 * H + K;
+    const size_t n = (size_t)rows * E;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / E;
+        const int c = (int)(i % E);
+        const int sc = c < H ? c : (c < H + K ? Hp + (c - H) : Hp + Kp + (c - H - K));
+        d_emb[r * Ep + sc] += dembc[r * ldc + c];
+    }
+}
+
+// dst[r][0:width] = src[r][col0 : col0+width]
+__global__ void unpad_copy_kernel(const float* __restrict__ src, int ld, int col0, int width,
+                                  float* __restrict__ dst, size_t rows) {
+    const size_t n = rows * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / width;
+        const int c = (int)(i % width);
+        dst[i] = src[r * ld + col0 + c];
+    }
+}
+
+static int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 16); }
+
+int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, float* embc, int ldc, int rows,
+                       hipStream_t stream) {
+    if (rows <= 0) return SHIVAE_OK;
+    hipLaunchKernelGGL(compact_emb_kernel, dim3(grid_for((size_t)rows * (2 * H + K))), dim3(256), 0, stream, emb,
+                       Ep, Hp, Kp, H, K, embc, ldc, rows);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+int launch_expand_add_emb(const float* dembc, int ldc, int H, int K, float* d_emb, int Ep, int Hp, int Kp, int rows,
+                          hipStream_t stream) {
+    if (rows <= 0) return SHIVAE_OK;
+    hipLaunchKernelGGL(expand_add_emb_kernel, dim3(grid_for((size_t)rows * (2 * H + K))), dim3(256), 0, stream,
+                       dembc, ldc, H, K, d_emb, Ep, Hp, Kp, rows);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+int launch_unpad_copy(const float* src, int ld, int col0, int width, float* dst, int64_t rows, hipStream_t stream) {
+    if (rows <= 0 || width <= 0) return SHIVAE_OK;
+    hipLaunchKernelGGL(unpad_copy_kernel, dim3(grid_for((size_t)rows * width)), dim3(256), 0, stream, src, ld, col0,
+                       width, dst, (size_t)rows);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// ---------------------------------------------------------------- global gradient norm (deterministic)
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ partial, int nparts,
+                                                           float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+int launch_sqnorm(const float* buf, int64_t n, float* scratch, float* out, hipStream_t stream) {
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256));
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(parts), dim3(256), 0, stream, buf, (size_t)n, scratch);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, scratch, parts, out);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// clip coefficient = min(clip / (norm + 1e-6), 1)  (torch clip_grad_norm_), then Adam (no weight
+// decay, no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, const float* __restrict__ sqnorm, float clip,
+                                 float step_size, float inv_sqrt_bc2, float b1, float b2, float eps) {
+    const float norm = sqrtf(sqnorm[0]);
+    const float coef = clip > 0.f ? fminf(clip / (norm + 1e-6f), 1.f) : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm, float clip,
+                     float lr, float b1, float b2, float eps, int step, hipStream_t stream) {
+    if (n <= 0) return SHIVAE_OK;
+    SV_REQUIRE(step >= 1, "clip_adam: step must be >= 1");
+    const double bc1 = 1.0 - std::pow((double)b1, step), bc2 = 1.0 - std::pow((double)b2, step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
+                       sqnorm, clip, (float)(lr / bc1), (float)(1.0 / std::sqrt(bc2)), b1, b2, eps);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+}  // namespace shivae

@@ -1,0 +1,812 @@
+// Plan (model description, flat parameter layout, workspace carving, static group tables) and the
+// host-side orchestration of one ELBO forward+backward step, exported through the C ABI of
+// include/shivae_hip.h.
+//
+// Order of one step (reference: trainers.py:212-215 -> base_missvae.py:144-231 -> shivae.py:72-154):
+//   pack scan weights | hoisted phi_x GEMMs | scan forward | per row-chunk: {compact emb, prior,
+//   KL terms (+grads), decoder forward, masked NLL (+grads), decoder backward, prior backward,
+//   scatter d_emb} | scan backward | batched weight gradients of the cell + phi_x backward | loss sums.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace shivae {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Tensor {
+    int64_t off = -1;
+    int rows = 0, cols = 0;
+};
+
+struct GroupTable {  // device table of GemmGroup + matching bias-gradient table
+    GemmGroup* dev = nullptr;
+    int n = 0;
+    int unaligned = 0;
+};
+struct ColTable {
+    ColsumGroup* dev = nullptr;
+    int n = 0;
+};
+
+}  // namespace shivae
+
+using namespace shivae;
+
+struct shivae_plan {
+    int T, B, H, Z, K, X, D, P, E, Hp, Zp, Kp, Ep, E4, Z4, learn_std;
+    int64_t R;
+    int Rc;
+    int nbc;  // attributes with a hidden head layer (bin/cat)
+    std::vector<AttrDesc> attrs;
+    std::vector<int> bc_index;  // attr -> index among bin/cat, or -1
+    std::vector<int> bc_attr;   // inverse
+    // parameter layout
+    Tensor glob[SHIVAE_P_COUNT];
+    std::vector<Tensor> per_attr[SHIVAE_P_COUNT];
+    int64_t n_params = 0;
+    // workspace
+    size_t ws_bytes = 0;
+    std::map<std::string, size_t> ws_off;
+    char* ws = nullptr;
+    float *params = nullptr, *grads = nullptr;
+    bool bound = false;
+    int last_flags = 0;
+    // device tables (library-owned)
+    AttrDesc* attrs_dev = nullptr;
+    PackJob *wjobs_dev = nullptr, *bjobs_dev = nullptr;
+    int n_wjobs = 0, n_bjobs = 0;
+    ScanWOff woff;
+    size_t wpack_floats = 0;
+    std::vector<void*> owned;  // device allocations to free
+    // grouped-GEMM tables
+    GroupTable f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
+    ColTable c_l1, c_l2, c_h0;
+    std::map<int, GroupTable> f_out, b_out_w, b_out_d;  // keyed by nout
+    std::map<int, ColTable> c_out;
+
+    float* wsf(const char* name) const { return reinterpret_cast<float*>(ws + ws_off.at(name)); }
+    float* prm(const Tensor& t) const { return params + t.off; }
+    float* grd(const Tensor& t) const { return grads + t.off; }
+};
+
+namespace shivae {
+
+static int64_t add_tensor(shivae_plan* p, Tensor& t, int rows, int cols) {
+    p->n_params = round_up64(p->n_params, 4);
+    t.off = p->n_params;
+    t.rows = rows;
+    t.cols = cols;
+    p->n_params += (int64_t)rows * cols;
+    return t.off;
+}
+
+static void build_layout(shivae_plan* p) {
+    const int H = p->H, Z = p->Z, K = p->K, X = p->X, D = p->D, E = p->E;
+    auto G = [&](int id, int r, int c) { add_tensor(p, p->glob[id], r, c); };
+    G(SHIVAE_P_PHIX0_W, H, X); G(SHIVAE_P_PHIX0_B, 1, H);
+    G(SHIVAE_P_PHIX2_W, H, H); G(SHIVAE_P_PHIX2_B, 1, H);
+    G(SHIVAE_P_XS0_W, H, X + H); G(SHIVAE_P_XS0_B, 1, H);
+    G(SHIVAE_P_XS2_W, K, H); G(SHIVAE_P_XS2_B, 1, K);
+    G(SHIVAE_P_E0_W, H, E); G(SHIVAE_P_E0_B, 1, H);
+    G(SHIVAE_P_E2_W, H, H); G(SHIVAE_P_E2_B, 1, H);
+    G(SHIVAE_P_ENCMEAN_W, Z, H); G(SHIVAE_P_ENCMEAN_B, 1, Z);
+    G(SHIVAE_P_ENCSTD_W, Z, H); G(SHIVAE_P_ENCSTD_B, 1, Z);
+    G(SHIVAE_P_PHIZ_W, H, Z); G(SHIVAE_P_PHIZ_B, 1, H);
+    G(SHIVAE_P_PRIOR0_W, H, H + K); G(SHIVAE_P_PRIOR0_B, 1, H);
+    G(SHIVAE_P_PRIORMEAN_W, Z, H); G(SHIVAE_P_PRIORMEAN_B, 1, Z);
+    G(SHIVAE_P_PRIORSTD_W, Z, H); G(SHIVAE_P_PRIORSTD_B, 1, Z);
+    G(SHIVAE_P_RNN_WIH, 4 * H, H); G(SHIVAE_P_RNN_WHH, 4 * H, H);
+    G(SHIVAE_P_RNN_BIH, 1, 4 * H); G(SHIVAE_P_RNN_BHH, 1, 4 * H);
+    // decoder: every kind stacked over the attributes (uniform stride) so that layer 0 of ALL
+    // attributes is one [D*2H, E] matrix and the heads' output rows form one [P, H] matrix.
+    auto stack = [&](int id, int rows, int cols, int count) {
+        Tensor base;
+        add_tensor(p, base, rows * count, cols);
+        p->glob[id] = base;
+        p->per_attr[id].assign(D, Tensor());
+        return base;
+    };
+    Tensor t;
+    t = stack(SHIVAE_P_DEC0_W, 2 * H, E, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC0_W][d] = Tensor{t.off + (int64_t)d * 2 * H * E, 2 * H, E};
+    t = stack(SHIVAE_P_DEC0_B, 1, 2 * H, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC0_B][d] = Tensor{t.off + (int64_t)d * 2 * H, 1, 2 * H};
+    t = stack(SHIVAE_P_DEC2_W, H, 2 * H, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC2_W][d] = Tensor{t.off + (int64_t)d * H * 2 * H, H, 2 * H};
+    t = stack(SHIVAE_P_DEC2_B, 1, H, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC2_B][d] = Tensor{t.off + (int64_t)d * H, 1, H};
+    t = stack(SHIVAE_P_DEC4_W, H, H, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC4_W][d] = Tensor{t.off + (int64_t)d * H * H, H, H};
+    t = stack(SHIVAE_P_DEC4_B, 1, H, D);
+    for (int d = 0; d < D; ++d) p->per_attr[SHIVAE_P_DEC4_B][d] = Tensor{t.off + (int64_t)d * H, 1, H};
+    t = stack(SHIVAE_P_HEAD0_W, H, H, std::max(p->nbc, 1));
+    for (int d = 0; d < D; ++d)
+        if (p->bc_index[d] >= 0) p->per_attr[SHIVAE_P_HEAD0_W][d] = Tensor{t.off + (int64_t)p->bc_index[d] * H * H, H, H};
+    t = stack(SHIVAE_P_HEAD0_B, 1, H, std::max(p->nbc, 1));
+    for (int d = 0; d < D; ++d)
+        if (p->bc_index[d] >= 0) p->per_attr[SHIVAE_P_HEAD0_B][d] = Tensor{t.off + (int64_t)p->bc_index[d] * H, 1, H};
+    // head output rows: [P, H] in attribute order; views by kind
+    Tensor wout, bout;
+    add_tensor(p, wout, p->P, H);
+    add_tensor(p, bout, 1, p->P);
+    for (int id : {SHIVAE_P_HEADMEAN_W, SHIVAE_P_HEADMEAN_B, SHIVAE_P_HEADSTD_W, SHIVAE_P_HEADSTD_B,
+                   SHIVAE_P_HEADOUT_W, SHIVAE_P_HEADOUT_B})
+        p->per_attr[id].assign(D, Tensor());
+    p->glob[SHIVAE_P_HEADOUT_W] = wout;
+    p->glob[SHIVAE_P_HEADOUT_B] = bout;
+    for (int d = 0; d < D; ++d) {
+        const AttrDesc& a = p->attrs[d];
+        if (a.type <= SHIVAE_POS) {
+            p->per_attr[SHIVAE_P_HEADMEAN_W][d] = Tensor{wout.off + (int64_t)a.poff * H, 1, H};
+            p->per_attr[SHIVAE_P_HEADMEAN_B][d] = Tensor{bout.off + a.poff, 1, 1};
+            if (p->learn_std) {
+                p->per_attr[SHIVAE_P_HEADSTD_W][d] = Tensor{wout.off + (int64_t)(a.poff + 1) * H, 1, H};
+                p->per_attr[SHIVAE_P_HEADSTD_B][d] = Tensor{bout.off + a.poff + 1, 1, 1};
+            }
+        } else {
+            p->per_attr[SHIVAE_P_HEADOUT_W][d] = Tensor{wout.off + (int64_t)a.poff * H, a.nout, H};
+            p->per_attr[SHIVAE_P_HEADOUT_B][d] = Tensor{bout.off + a.poff, 1, a.nout};
+        }
+    }
+    p->n_params = round_up64(p->n_params, 4);
+}
+
+static void carve(shivae_plan* p, const char* name, size_t floats, size_t& cur) {
+    p->ws_off[name] = cur;
+    cur += round_up64((int64_t)(floats * sizeof(float)), 256);
+}
+
+static void build_workspace(shivae_plan* p) {
+    size_t cur = 0;
+    const size_t R = (size_t)p->R, Rc = (size_t)p->Rc, Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep;
+    const size_t H = p->H, D = p->D;
+    for (const char* n : {"p1", "phx", "xs_pre", "ex_pre", "as", "e1", "e2", "cnew", "d_phiz_pre", "d_e2_pre",
+                          "d_e1_pre", "d_as_pre", "d_phx_pre", "d_p1_pre"})
+        carve(p, n, R * Hp, cur);
+    carve(p, "emb", R * Ep, cur);
+    carve(p, "d_emb", R * Ep, cur);
+    carve(p, "gates", R * 4 * Hp, cur);
+    carve(p, "d_gates", R * 4 * Hp, cur);
+    for (const char* n : {"mu", "sd", "z", "mup", "sdp", "dmu_ext", "dsd_ext", "d_mu", "d_sd_pre"}) carve(p, n, R * Zp, cur);
+    for (const char* n : {"logits", "probs", "dlg_kl", "d_lg_pre"}) carve(p, n, R * Kp, cur);
+    carve(p, "rowloss", R * 6, cur);
+    carve(p, "persum", (size_t)p->B * 6, cur);
+    carve(p, "pfull", R * p->P, cur);
+    // chunk-local
+    carve(p, "embc", Rc * p->E4, cur);
+    carve(p, "dembc", Rc * p->E4, cur);
+    carve(p, "prc", Rc * Hp, cur);
+    carve(p, "dprc", Rc * Hp, cur);
+    carve(p, "dmupc", Rc * Zp, cur);
+    carve(p, "dsdp_prec", Rc * Zp, cur);
+    carve(p, "a0", Rc * D * 2 * H, cur);
+    carve(p, "da0", Rc * D * 2 * H, cur);
+    for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Rc * D * H, cur);
+    carve(p, "hh", Rc * std::max(p->nbc, 1) * H, cur);
+    carve(p, "dhh", Rc * std::max(p->nbc, 1) * H, cur);
+    carve(p, "pbuf", Rc * p->P, cur);
+    carve(p, "wpack", p->wpack_floats, cur);
+    p->ws_bytes = cur;
+}
+
+// ------------------------------------------------------------ packed scan weights: offsets + jobs
+static void build_pack_plan(shivae_plan* p, std::vector<PackJob>& wj, std::vector<PackJob>& bj, bool with_ptrs) {
+    const int H = p->H, Z = p->Z, K = p->K, X = p->X, Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, E = p->E;
+    int cur = 0;
+    auto W = [&](int& off, const Tensor& t, int col0, int O, int Op, int I, int Ip, bool transposed, int oblocks,
+                 int iblocks) {
+        // (O, I) = true out/in extents of the PACKED operator; for transposed jobs the source is [I rows, O cols]
+        off = cur;
+        PackJob j;
+        memset(&j, 0, sizeof(j));
+        j.src = with_ptrs ? p->params + t.off + col0 : nullptr;
+        j.ld = t.cols;
+        j.transposed = transposed;
+        j.Op = Op * oblocks; j.Ip = Ip * iblocks;
+        j.oblk_true = O; j.oblk_pad = Op; j.iblk_true = I; j.iblk_pad = Ip;
+        j.dst_off = cur;
+        wj.push_back(j);
+        cur += j.Op * j.Ip;
+    };
+    auto Bv = [&](int& off, const Tensor& t, const Tensor* t2, int O, int Op, int oblocks) {
+        off = cur;
+        PackJob j;
+        memset(&j, 0, sizeof(j));
+        j.src = with_ptrs ? p->params + t.off : nullptr;
+        j.src2 = (with_ptrs && t2) ? p->params + t2->off : nullptr;
+        j.Op = Op * oblocks; j.oblk_true = O; j.oblk_pad = Op;
+        j.iblk_true = j.iblk_pad = 1;
+        j.dst_off = cur;
+        bj.push_back(j);
+        cur += round_up(j.Op, 4);
+    };
+    ScanWOff& w = p->woff;
+    const Tensor* g = p->glob;
+    // forward images: out = rows of W
+    W(w.xsh, g[SHIVAE_P_XS0_W], X, H, Hp, H, Hp, false, 1, 1);          // Wxs0[:, X:]   (encoders.py:54)
+    W(w.lg, g[SHIVAE_P_XS2_W], 0, K, Kp, H, Hp, false, 1, 1);
+    Bv(w.b_lg, g[SHIVAE_P_XS2_B], nullptr, K, Kp, 1);
+    W(w.e0s, g[SHIVAE_P_E0_W], H, H, Hp, K, Kp, false, 1, 1);           // We0[:, H:H+K] (encoders.py:61)
+    W(w.e0h, g[SHIVAE_P_E0_W], H + K, H, Hp, H, Hp, false, 1, 1);       // We0[:, H+K:]
+    W(w.e2, g[SHIVAE_P_E2_W], 0, H, Hp, H, Hp, false, 1, 1);
+    Bv(w.b_e2, g[SHIVAE_P_E2_B], nullptr, H, Hp, 1);
+    W(w.mu, g[SHIVAE_P_ENCMEAN_W], 0, Z, Zp, H, Hp, false, 1, 1);
+    Bv(w.b_mu, g[SHIVAE_P_ENCMEAN_B], nullptr, Z, Zp, 1);
+    W(w.sd, g[SHIVAE_P_ENCSTD_W], 0, Z, Zp, H, Hp, false, 1, 1);
+    Bv(w.b_sd, g[SHIVAE_P_ENCSTD_B], nullptr, Z, Zp, 1);
+    W(w.pz, g[SHIVAE_P_PHIZ_W], 0, H, Hp, Z, Zp, false, 1, 1);
+    Bv(w.b_pz, g[SHIVAE_P_PHIZ_B], nullptr, H, Hp, 1);
+    W(w.ih, g[SHIVAE_P_RNN_WIH], 0, H, Hp, H, Hp, false, 4, 1);         // 4 gate blocks of rows
+    W(w.hh, g[SHIVAE_P_RNN_WHH], 0, H, Hp, H, Hp, false, 4, 1);
+    Bv(w.b_g, g[SHIVAE_P_RNN_BIH], &g[SHIVAE_P_RNN_BHH], H, Hp, 4);
+    // transposed images for the backward: out = columns of W
+    W(w.t_ih, g[SHIVAE_P_RNN_WIH], 0, H, Hp, H, Hp, true, 1, 4);
+    W(w.t_hh, g[SHIVAE_P_RNN_WHH], 0, H, Hp, H, Hp, true, 1, 4);
+    W(w.t_pz, g[SHIVAE_P_PHIZ_W], 0, Z, Zp, H, Hp, true, 1, 1);
+    W(w.t_mu, g[SHIVAE_P_ENCMEAN_W], 0, H, Hp, Z, Zp, true, 1, 1);
+    W(w.t_sd, g[SHIVAE_P_ENCSTD_W], 0, H, Hp, Z, Zp, true, 1, 1);
+    W(w.t_e2, g[SHIVAE_P_E2_W], 0, H, Hp, H, Hp, true, 1, 1);
+    W(w.t_e0s, g[SHIVAE_P_E0_W], H, K, Kp, H, Hp, true, 1, 1);
+    W(w.t_e0h, g[SHIVAE_P_E0_W], H + K, H, Hp, H, Hp, true, 1, 1);
+    W(w.t_lg, g[SHIVAE_P_XS2_W], 0, H, Hp, K, Kp, true, 1, 1);
+    W(w.t_xsh, g[SHIVAE_P_XS0_W], X, H, Hp, H, Hp, true, 1, 1);
+    (void)E;
+    p->wpack_floats = cur;
+}
+
+template <class T>
+static int upload(shivae_plan* p, const std::vector<T>& host, T** dev) {
+    *dev = nullptr;
+    if (host.empty()) return SHIVAE_OK;
+    SV_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(T)));
+    p->owned.push_back(*dev);
+    SV_CHECK_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SHIVAE_OK;
+}
+
+static int make_table(shivae_plan* p, const std::vector<GemmGroup>& g, GroupTable& t) {
+    t.n = (int)g.size();
+    t.unaligned = 0;
+    for (const GemmGroup& x : g)
+        if ((reinterpret_cast<uintptr_t>(x.A) | reinterpret_cast<uintptr_t>(x.B)) & 15) t.unaligned = 1;
+    return upload(p, g, &t.dev);
+}
+static int make_ctable(shivae_plan* p, const std::vector<ColsumGroup>& g, ColTable& t) {
+    t.n = (int)g.size();
+    return upload(p, g, &t.dev);
+}
+
+static int build_tables(shivae_plan* p) {
+    const int H = p->H, D = p->D;
+    float *a0 = p->wsf("a0"), *a1 = p->wsf("a1"), *a2 = p->wsf("a2"), *hh = p->wsf("hh"), *pb = p->wsf("pbuf");
+    float *da0 = p->wsf("da0"), *da1 = p->wsf("da1"), *da2 = p->wsf("da2"), *dhh = p->wsf("dhh");
+    auto PA = [&](int id, int d) { return p->params + p->per_attr[id][d].off; };
+    auto GA = [&](int id, int d) { return p->grads + p->per_attr[id][d].off; };
+    std::vector<GemmGroup> fl1, fl2, fh0, wl1, dl1, wl2, dl2, wh0, dh0;
+    std::vector<ColsumGroup> cl1, cl2, ch0;
+    std::map<int, std::vector<GemmGroup>> fo, wo, dO;
+    std::map<int, std::vector<ColsumGroup>> co;
+    for (int d = 0; d < D; ++d) {
+        const AttrDesc& a = p->attrs[d];
+        float *a0d = a0 + (size_t)d * 2 * H, *a1d = a1 + (size_t)d * H, *a2d = a2 + (size_t)d * H;
+        float *da0d = da0 + (size_t)d * 2 * H, *da1d = da1 + (size_t)d * H, *da2d = da2 + (size_t)d * H;
+        // trunk (decoders.py:60-66)
+        fl1.push_back({a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr});
+        fl2.push_back({a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr});
+        wl2.push_back({da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr});
+        cl2.push_back({da2d, GA(SHIVAE_P_DEC4_B, d)});
+        dl2.push_back({da2d, PA(SHIVAE_P_DEC4_W, d), da1d, nullptr, a1d});
+        wl1.push_back({da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr});
+        cl1.push_back({da1d, GA(SHIVAE_P_DEC2_B, d)});
+        dl1.push_back({da1d, PA(SHIVAE_P_DEC2_W, d), da0d, nullptr, a0d});
+        // heads (decoders.py:69-102)
+        float* wout = p->params + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
+        float* bout = p->params + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
+        float* gwout = p->grads + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
+        float* gbout = p->grads + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
+        float* pd = pb + a.poff;
+        const float* hin = a2d;
+        float *dhin = da2d, *hmask = a2d;
+        if (p->bc_index[d] >= 0) {
+            const int jx = p->bc_index[d];
+            float *hhj = hh + (size_t)jx * H, *dhhj = dhh + (size_t)jx * H;
+            fh0.push_back({a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr});
+            wh0.push_back({dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr});
+            ch0.push_back({dhhj, GA(SHIVAE_P_HEAD0_B, d)});
+            dh0.push_back({dhhj, PA(SHIVAE_P_HEAD0_W, d), da2d, nullptr, a2d});
+            hin = hhj; dhin = dhhj; hmask = hhj;
+        }
+        // tables are keyed by +nout (input = hh, bin/cat) or -nout (input = a2, real/pos): the two
+        // inputs have different leading dimensions, and a grouped launch shares them
+        const int key = p->bc_index[d] >= 0 ? a.nout : -a.nout;
+        fo[key].push_back({hin, wout, pd, bout, nullptr});
+        wo[key].push_back({pd, hin, gwout, nullptr, nullptr});
+        co[key].push_back({pd, gbout});
+        dO[key].push_back({pd, wout, dhin, nullptr, hmask});
+    }
+    SV_TRY(make_table(p, fl1, p->f_l1)); SV_TRY(make_table(p, fl2, p->f_l2)); SV_TRY(make_table(p, fh0, p->f_h0));
+    SV_TRY(make_table(p, wl1, p->b_l1_w)); SV_TRY(make_table(p, dl1, p->b_l1_d));
+    SV_TRY(make_table(p, wl2, p->b_l2_w)); SV_TRY(make_table(p, dl2, p->b_l2_d));
+    SV_TRY(make_table(p, wh0, p->b_h0_w)); SV_TRY(make_table(p, dh0, p->b_h0_d));
+    SV_TRY(make_ctable(p, cl1, p->c_l1)); SV_TRY(make_ctable(p, cl2, p->c_l2)); SV_TRY(make_ctable(p, ch0, p->c_h0));
+    for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first]));
+    for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first]));
+    for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first]));
+    for (auto& kv : co) SV_TRY(make_ctable(p, kv.second, p->c_out[kv.first]));
+    return SHIVAE_OK;
+}
+
+// ------------------------------------------------------------ GEMM helpers
+static int splitk_for(int M, int N, int K, int groups) {
+    const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * groups;
+    int sk = ceil_div(1024, tiles);
+    sk = std::min(sk, ceil_div(K, 512));
+    sk = std::min(sk, 65535 / std::max(groups, 1));
+    return std::max(sk, 1);
+}
+
+static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* aux, int ldaux, int epi, hipStream_t s) {
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, 0};
+    if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, 1);
+    GemmGroup g{A, B, C, bias, aux};
+    return launch_gemm(d, nullptr, 1, g, s);
+}
+static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epi, const GroupTable& t,
+                 hipStream_t s) {
+    if (t.n == 0) return SHIVAE_OK;
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned};
+    if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, t.n);
+    return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
+}
+static int colsum1(int M, int N, int ld, const float* Y, float* out, hipStream_t s) {
+    return launch_colsum(M, N, ld, nullptr, 1, ColsumGroup{Y, out}, s);
+}
+static int colsumg(int M, int N, int ld, const ColTable& t, hipStream_t s) {
+    if (t.n == 0) return SHIVAE_OK;
+    return launch_colsum(M, N, ld, t.dev, t.n, ColsumGroup{}, s);
+}
+
+static ScanArgs scan_args(shivae_plan* p, const float* u, const float* eps, float temp) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.T = p->T; a.B = p->B; a.H = p->H; a.Z = p->Z; a.K = p->K;
+    a.Hp = p->Hp; a.Zp = p->Zp; a.Kp = p->Kp; a.Ep = p->Ep; a.temp = temp;
+    a.wpack = p->wsf("wpack"); a.w = p->woff;
+    a.xs_pre = p->wsf("xs_pre"); a.ex_pre = p->wsf("ex_pre"); a.u = u; a.eps = eps;
+    a.emb = p->wsf("emb"); a.as_ = p->wsf("as"); a.e1 = p->wsf("e1"); a.e2 = p->wsf("e2");
+    a.logits = p->wsf("logits"); a.probs = p->wsf("probs"); a.mu = p->wsf("mu"); a.sd = p->wsf("sd");
+    a.z = p->wsf("z"); a.gates = p->wsf("gates"); a.cnew = p->wsf("cnew"); a.h_last = nullptr;
+    a.d_emb = p->wsf("d_emb"); a.dmu_ext = p->wsf("dmu_ext"); a.dsd_ext = p->wsf("dsd_ext"); a.dlg_kl = p->wsf("dlg_kl");
+    a.d_gates = p->wsf("d_gates"); a.d_phiz_pre = p->wsf("d_phiz_pre"); a.d_mu = p->wsf("d_mu");
+    a.d_sd_pre = p->wsf("d_sd_pre"); a.d_e2_pre = p->wsf("d_e2_pre"); a.d_e1_pre = p->wsf("d_e1_pre");
+    a.d_lg_pre = p->wsf("d_lg_pre"); a.d_as_pre = p->wsf("d_as_pre");
+    return a;
+}
+
+// ------------------------------------------------------------ the step
+static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float* u, const float* eps, float beta,
+                float temp, float inv_batch, int flags, float* losses, hipStream_t s) {
+    const bool grad = !(flags & SHIVAE_STEP_FORWARD_ONLY);
+    const bool keep = flags & SHIVAE_STEP_KEEP_PARAMS;
+    const int H = p->H, Z = p->Z, K = p->K, X = p->X, D = p->D, E = p->E, P = p->P;
+    const int Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep, E4 = p->E4;
+    const int R = (int)p->R;
+    const Tensor* g = p->glob;
+    const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
+
+    // 0. scan weights in MFMA operand order (parameters change every optimiser step)
+    SV_TRY(launch_pack(p->wjobs_dev, p->n_wjobs, p->bjobs_dev, p->n_bjobs, p->wsf("wpack"), s));
+
+    // 1. h-independent encoder parts, batched over all T*B rows (encoders.py:82, x/phi_x halves of :83,:91)
+    float *p1 = p->wsf("p1"), *phx = p->wsf("phx"), *xs_pre = p->wsf("xs_pre"), *ex_pre = p->wsf("ex_pre");
+    SV_TRY(gemm1(NT, R, H, X, x, X, p->prm(g[SHIVAE_P_PHIX0_W]), X, p1, Hp, p->prm(g[SHIVAE_P_PHIX0_B]), nullptr, 0,
+                 EPI_BIAS | EPI_RELU, s));
+    SV_TRY(gemm1(NT, R, H, H, p1, Hp, p->prm(g[SHIVAE_P_PHIX2_W]), H, phx, Hp, p->prm(g[SHIVAE_P_PHIX2_B]), nullptr, 0,
+                 EPI_BIAS | EPI_RELU, s));
+    SV_TRY(gemm1(NT, R, H, X, x, X, p->prm(g[SHIVAE_P_XS0_W]), X + H, xs_pre, Hp, p->prm(g[SHIVAE_P_XS0_B]), nullptr, 0,
+                 EPI_BIAS, s));
+    SV_TRY(gemm1(NT, R, H, H, phx, Hp, p->prm(g[SHIVAE_P_E0_W]), E, ex_pre, Hp, p->prm(g[SHIVAE_P_E0_B]), nullptr, 0,
+                 EPI_BIAS, s));
+
+    // 2. the serial chain
+    ScanArgs sa = scan_args(p, u, eps, temp);
+    SV_TRY(launch_scan(sa, false, s));
+
+    float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
+    if (grad) SV_CHECK_HIP(hipMemsetAsync(d_emb, 0, (size_t)R * Ep * sizeof(float), s));
+
+    // 3. everything that only feeds the loss, in row chunks (prior shivae.py:124-127; decoder
+    //    decoders.py:109-176; losses base_missvae.py:233-343) with its backward right behind it
+    float *embc = p->wsf("embc"), *dembc = p->wsf("dembc"), *prc = p->wsf("prc"), *dprc = p->wsf("dprc");
+    float *mup = p->wsf("mup"), *sdp = p->wsf("sdp"), *dmupc = p->wsf("dmupc"), *dsdpc = p->wsf("dsdp_prec");
+    float *a0 = p->wsf("a0"), *a1 = p->wsf("a1"), *a2 = p->wsf("a2"), *pbuf = p->wsf("pbuf");
+    float *da0 = p->wsf("da0");
+    const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
+                *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
+    const float kz = beta * inv_batch;
+    const int ldA0 = D * 2 * H, ldA1 = D * H, ldHH = std::max(p->nbc, 1) * H;
+    for (int r0 = 0; r0 < R; r0 += p->Rc) {
+        const int rc = std::min(p->Rc, R - r0);
+        SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
+        const float *emb_z = embc, *emb_s = embc + H, *emb_h = embc + H + K;
+        (void)emb_z;
+        // prior.0 takes cat[h, s] (shivae.py:124): columns [0,H) of its weight act on h, [H,H+K) on s
+        SV_TRY(gemm1(NT, rc, H, H, emb_h, E4, Wp0, H + K, prc, Hp, nullptr, nullptr, 0, 0, s));
+        SV_TRY(gemm1(NT, rc, H, K, emb_s, E4, Wp0 + H, H + K, prc, Hp, p->prm(g[SHIVAE_P_PRIOR0_B]), nullptr, 0,
+                     EPI_BIAS | EPI_ADDC | EPI_RELU, s));
+        float *mupc = mup + (size_t)r0 * Zp, *sdpc = sdp + (size_t)r0 * Zp;
+        SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wpm, H, mupc, Zp, p->prm(g[SHIVAE_P_PRIORMEAN_B]), nullptr, 0, EPI_BIAS, s));
+        SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wps, H, sdpc, Zp, p->prm(g[SHIVAE_P_PRIORSTD_B]), nullptr, 0,
+                     EPI_BIAS | EPI_SOFTPLUS, s));
+        SV_TRY(launch_kl(p->wsf("mu") + (size_t)r0 * Zp, p->wsf("sd") + (size_t)r0 * Zp, mupc, sdpc, Zp,
+                         p->wsf("probs") + (size_t)r0 * Kp, Kp, grad ? p->wsf("dmu_ext") + (size_t)r0 * Zp : nullptr,
+                         grad ? p->wsf("dsd_ext") + (size_t)r0 * Zp : nullptr, grad ? dmupc : nullptr,
+                         grad ? dsdpc : nullptr, grad ? p->wsf("dlg_kl") + (size_t)r0 * Kp : nullptr, rc, Z, K, kz,
+                         rowloss + (size_t)r0 * 6, s));
+        // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
+        SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
+                     nullptr, 0, EPI_BIAS | EPI_RELU, s));
+        SV_TRY(gemmg(NT, rc, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s));
+        for (auto& kv : p->f_out) {
+            const int key = kv.first, nout = key < 0 ? -key : key;
+            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s));
+        }
+        if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
+                                              hipMemcpyDeviceToDevice, s));
+        SV_TRY(launch_heter_nll(p->attrs_dev, D, p->learn_std, x + (size_t)r0 * X, X, mask + (size_t)r0 * X, X, pbuf, P,
+                                grad ? pbuf : nullptr, P, rc, inv_batch, rowloss + (size_t)r0 * 6, s));
+        if (!grad) continue;
+
+        // ---- decoder backward (pbuf now holds d nll / d head outputs) ----
+        for (auto& kv : p->b_out_w) {
+            const int key = kv.first, nout = key < 0 ? -key : key, ldin = key < 0 ? ldA1 : ldHH;
+            SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s));
+            SV_TRY(colsumg(rc, nout, P, p->c_out[key], s));
+            // d(head input) = dP * Wout, gated by the head input's ReLU
+            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK, p->b_out_d[key], s));
+        }
+        SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s));
+        SV_TRY(colsumg(rc, H, ldHH, p->c_h0, s));
+        SV_TRY(gemmg(NN, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK, p->b_h0_d, s));
+        SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s));
+        SV_TRY(colsumg(rc, H, ldA1, p->c_l2, s));
+        SV_TRY(gemmg(NN, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK, p->b_l2_d, s));
+        SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s));
+        SV_TRY(colsumg(rc, H, ldA1, p->c_l1, s));
+        SV_TRY(gemmg(NN, rc, 2 * H, H, ldA1, 2 * H, ldA0, ldA0, EPI_MASK, p->b_l1_d, s));
+        // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
+        SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
+                     EPI_ATOMIC, s));
+        SV_TRY(colsum1(rc, D * 2 * H, ldA0, da0, p->grd(g[SHIVAE_P_DEC0_B]), s));
+        SV_TRY(gemm1(NN, rc, E, D * 2 * H, da0, ldA0, p->prm(g[SHIVAE_P_DEC0_W]), E, dembc, E4, nullptr, nullptr, 0, 0, s));
+
+        // ---- prior backward ----
+        SV_TRY(gemm1(NN, rc, H, Z, dmupc, Zp, Wpm, H, dprc, Hp, nullptr, nullptr, 0, 0, s));
+        SV_TRY(gemm1(NN, rc, H, Z, dsdpc, Zp, Wps, H, dprc, Hp, nullptr, prc, Hp, EPI_ADDC | EPI_MASK, s));
+        SV_TRY(gemm1(TN, Z, H, rc, dmupc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(gemm1(TN, Z, H, rc, dsdpc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(rc, Z, Zp, dmupc, p->grd(g[SHIVAE_P_PRIORMEAN_B]), s));
+        SV_TRY(colsum1(rc, Z, Zp, dsdpc, p->grd(g[SHIVAE_P_PRIORSTD_B]), s));
+        float* gWp0 = p->grd(g[SHIVAE_P_PRIOR0_W]);
+        SV_TRY(gemm1(TN, H, H, rc, dprc, Hp, emb_h, E4, gWp0, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(gemm1(TN, H, K, rc, dprc, Hp, emb_s, E4, gWp0 + H, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(rc, H, Hp, dprc, p->grd(g[SHIVAE_P_PRIOR0_B]), s));
+        SV_TRY(gemm1(NN, rc, H, H, dprc, Hp, Wp0, H + K, dembc + H + K, E4, nullptr, nullptr, 0, EPI_ADDC, s));
+        SV_TRY(gemm1(NN, rc, K, H, dprc, Hp, Wp0 + H, H + K, dembc + H, E4, nullptr, nullptr, 0, EPI_ADDC, s));
+        SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
+    }
+
+    if (grad) {
+        // 4. reverse-time scan
+        SV_TRY(launch_scan(sa, true, s));
+        // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics)
+        const float *phiz = emb, *s_t = emb + Hp, *hprev = emb + Hp + Kp;
+        float *d_gates = p->wsf("d_gates"), *d_phz = p->wsf("d_phiz_pre"), *d_mu = p->wsf("d_mu"),
+              *d_sd = p->wsf("d_sd_pre"), *d_e2 = p->wsf("d_e2_pre"), *d_e1 = p->wsf("d_e1_pre"),
+              *d_lg = p->wsf("d_lg_pre"), *d_as = p->wsf("d_as_pre");
+        for (int gt = 0; gt < 4; ++gt) {  // gate blocks are padded H -> Hp in the records
+            const float* dg = d_gates + gt * Hp;
+            SV_TRY(gemm1(TN, H, H, R, dg, 4 * Hp, phiz, Ep, p->grd(g[SHIVAE_P_RNN_WIH]) + (size_t)gt * H * H, H, nullptr,
+                         nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(gemm1(TN, H, H, R, dg, 4 * Hp, hprev, Ep, p->grd(g[SHIVAE_P_RNN_WHH]) + (size_t)gt * H * H, H, nullptr,
+                         nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BIH]) + gt * H, s));
+            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BHH]) + gt * H, s));
+        }
+        SV_TRY(gemm1(TN, H, Z, R, d_phz, Hp, p->wsf("z"), Zp, p->grd(g[SHIVAE_P_PHIZ_W]), Z, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_phz, p->grd(g[SHIVAE_P_PHIZ_B]), s));
+        SV_TRY(gemm1(TN, Z, H, R, d_mu, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, Z, Zp, d_mu, p->grd(g[SHIVAE_P_ENCMEAN_B]), s));
+        SV_TRY(gemm1(TN, Z, H, R, d_sd, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, Z, Zp, d_sd, p->grd(g[SHIVAE_P_ENCSTD_B]), s));
+        SV_TRY(gemm1(TN, H, H, R, d_e2, Hp, p->wsf("e1"), Hp, p->grd(g[SHIVAE_P_E2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_e2, p->grd(g[SHIVAE_P_E2_B]), s));
+        float* gE0 = p->grd(g[SHIVAE_P_E0_W]);
+        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, phx, Hp, gE0, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(gemm1(TN, H, K, R, d_e1, Hp, s_t, Ep, gE0 + H, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, hprev, Ep, gE0 + H + K, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_e1, p->grd(g[SHIVAE_P_E0_B]), s));
+        SV_TRY(gemm1(TN, K, H, R, d_lg, Kp, p->wsf("as"), Hp, p->grd(g[SHIVAE_P_XS2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, K, Kp, d_lg, p->grd(g[SHIVAE_P_XS2_B]), s));
+        float* gXS0 = p->grd(g[SHIVAE_P_XS0_W]);
+        SV_TRY(gemm1(TN, H, X, R, d_as, Hp, x, X, gXS0, X + H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(gemm1(TN, H, H, R, d_as, Hp, hprev, Ep, gXS0 + X, X + H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_as, p->grd(g[SHIVAE_P_XS0_B]), s));
+        // 6. phi_x backward (encoders.py:47-51)
+        float *d_phx = p->wsf("d_phx_pre"), *d_p1 = p->wsf("d_p1_pre");
+        SV_TRY(gemm1(NN, R, H, H, d_e1, Hp, p->prm(g[SHIVAE_P_E0_W]), E, d_phx, Hp, nullptr, phx, Hp, EPI_MASK, s));
+        SV_TRY(gemm1(TN, H, H, R, d_phx, Hp, p1, Hp, p->grd(g[SHIVAE_P_PHIX2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_phx, p->grd(g[SHIVAE_P_PHIX2_B]), s));
+        SV_TRY(gemm1(NN, R, H, H, d_phx, Hp, p->prm(g[SHIVAE_P_PHIX2_W]), H, d_p1, Hp, nullptr, p1, Hp, EPI_MASK, s));
+        SV_TRY(gemm1(TN, H, X, R, d_p1, Hp, x, X, p->grd(g[SHIVAE_P_PHIX0_W]), X, nullptr, nullptr, 0, EPI_ATOMIC, s));
+        SV_TRY(colsum1(R, H, Hp, d_p1, p->grd(g[SHIVAE_P_PHIX0_B]), s));
+    }
+
+    // 7. sum per-timestep terms over t (fixed order), then the batch means (base_missvae.py:211-230)
+    SV_TRY(launch_loss_reduce(rowloss, p->wsf("persum"), p->T, p->B, beta, inv_batch, losses, s));
+    p->last_flags = flags;
+    return SHIVAE_OK;
+}
+
+}  // namespace shivae
+
+// =========================================================================== C ABI
+extern "C" {
+
+const char* shivae_last_error(void) { return g_err; }
+const char* shivae_version(void) { return "shivae_hip gfx950 " __DATE__ " " __TIME__; }
+
+int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
+    SV_REQUIRE(cfg && out, "plan_create: null argument");
+    SV_REQUIRE(cfg->T > 0 && cfg->B > 0 && cfg->H > 0 && cfg->Z > 0 && cfg->K > 0 && cfg->n_attr > 0,
+               "plan_create: T,B,H,Z,K,n_attr must be positive");
+    SV_REQUIRE(cfg->attr_type && cfg->attr_nclass, "plan_create: attribute tables missing");
+    SV_REQUIRE((int64_t)cfg->T * cfg->B < (1ll << 31) - 65536, "plan_create: T*B too large for one call; split the batch");
+    shivae_plan* p = new shivae_plan();
+    p->T = cfg->T; p->B = cfg->B; p->H = cfg->H; p->Z = cfg->Z; p->K = cfg->K; p->D = cfg->n_attr;
+    p->learn_std = cfg->learn_std ? 1 : 0;
+    p->R = (int64_t)p->T * p->B;
+    int xoff = 0, poff = 0;
+    p->nbc = 0;
+    for (int d = 0; d < p->D; ++d) {
+        AttrDesc a;
+        a.type = cfg->attr_type[d];
+        if (a.type < SHIVAE_REAL || a.type > SHIVAE_CAT) {
+            set_error("plan_create: attribute %d has unknown type %d", d, a.type);
+            delete p;
+            return SHIVAE_ERR_INVALID;
+        }
+        a.dim = a.type == SHIVAE_CAT ? cfg->attr_nclass[d] : 1;
+        if (a.type == SHIVAE_CAT && a.dim < 2) {
+            set_error("plan_create: categorical attribute %d needs nclass >= 2", d);
+            delete p;
+            return SHIVAE_ERR_INVALID;
+        }
+        a.nout = a.type <= SHIVAE_POS ? (p->learn_std ? 2 : 1) : (a.type == SHIVAE_BIN ? 1 : a.dim - 1);
+        a.xoff = xoff; a.poff = poff;
+        xoff += a.dim; poff += a.nout;
+        p->attrs.push_back(a);
+        const bool bc = a.type >= SHIVAE_BIN;
+        p->bc_index.push_back(bc ? p->nbc : -1);
+        if (bc) { p->bc_attr.push_back(d); p->nbc++; }
+    }
+    p->X = xoff; p->P = poff; p->E = 2 * p->H + p->K;
+    p->Hp = round_up(p->H, 16); p->Zp = round_up(p->Z, 16); p->Kp = round_up(p->K, 16);
+    p->Ep = 2 * p->Hp + p->Kp; p->E4 = round_up(p->E, 4); p->Z4 = round_up(p->Z, 4);
+    if (p->Hp > 512) {
+        set_error("plan_create: h_dim %d > 512 not supported by the recurrent kernel", p->H);
+        delete p;
+        return SHIVAE_ERR_INVALID;
+    }
+    build_layout(p);
+    {
+        std::vector<PackJob> wj, bj;
+        build_pack_plan(p, wj, bj, false);
+    }
+    // decoder row chunk: bytes per row of chunk-local activations
+    const double per_row = 4.0 * ((double)p->D * p->H * 8 + (double)std::max(p->nbc, 1) * p->H * 2 + p->P + 2.0 * p->E4 +
+                                  2.0 * p->Hp + 2.0 * p->Zp);
+    int rc = cfg->chunk_rows;
+    if (rc <= 0) {
+        const double budget = 40e9;  // bytes of chunk-local activations
+        rc = (int)std::min<double>((double)p->R, std::max(256.0, budget / per_row));
+        if (rc < p->R) rc = std::max(256, rc / 256 * 256);
+    }
+    p->Rc = (int)std::min<int64_t>(rc, p->R);
+    build_workspace(p);
+    *out = p;
+    return SHIVAE_OK;
+}
+
+void shivae_plan_destroy(shivae_plan* plan) {
+    if (!plan) return;
+    for (void* d : plan->owned) (void)hipFree(d);
+    delete plan;
+}
+
+int64_t shivae_plan_num_params(const shivae_plan* p) { return p ? p->n_params : 0; }
+int shivae_plan_x_dim(const shivae_plan* p) { return p ? p->X : 0; }
+int shivae_plan_p_dim(const shivae_plan* p) { return p ? p->P : 0; }
+int shivae_plan_chunk_rows(const shivae_plan* p) { return p ? p->Rc : 0; }
+size_t shivae_plan_workspace_bytes(const shivae_plan* p) { return p ? p->ws_bytes : 0; }
+
+int shivae_plan_param_info(const shivae_plan* p, int id, int attr, int64_t* offset, int* rows, int* cols) {
+    SV_REQUIRE(p && id >= 0 && id < SHIVAE_P_COUNT, "param_info: bad tensor id %d", id);
+    Tensor t;
+    if (id < SHIVAE_P_DEC0_W) t = p->glob[id];
+    else {
+        SV_REQUIRE(attr >= 0 && attr < p->D, "param_info: bad attribute %d", attr);
+        t = p->per_attr[id][attr];
+    }
+    SV_REQUIRE(t.off >= 0, "param_info: tensor %d does not exist for attribute %d", id, attr);
+    if (offset) *offset = t.off;
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    return SHIVAE_OK;
+}
+
+int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, float* grads) {
+    SV_REQUIRE(p && ws && params && grads, "plan_bind: null argument");
+    SV_REQUIRE(bytes >= p->ws_bytes, "plan_bind: workspace has %zu bytes, %zu needed", bytes, p->ws_bytes);
+    SV_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "plan_bind: workspace must be 256-B aligned");
+    SV_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0,
+               "plan_bind: parameter/gradient buffers must be 16-B aligned");
+    for (void* d : p->owned) (void)hipFree(d);
+    p->owned.clear();
+    p->f_out.clear(); p->b_out_w.clear(); p->b_out_d.clear(); p->c_out.clear();
+    p->ws = static_cast<char*>(ws);
+    p->params = params;
+    p->grads = grads;
+    // padding columns and the t=0 h_prev rows rely on the workspace starting at zero
+    SV_CHECK_HIP(hipMemset(ws, 0, p->ws_bytes));
+    SV_TRY(upload(p, p->attrs, &p->attrs_dev));
+    std::vector<PackJob> wj, bj;
+    build_pack_plan(p, wj, bj, true);
+    p->n_wjobs = (int)wj.size(); p->n_bjobs = (int)bj.size();
+    SV_TRY(upload(p, wj, &p->wjobs_dev));
+    SV_TRY(upload(p, bj, &p->bjobs_dev));
+    SV_TRY(build_tables(p));
+    SV_CHECK_HIP(hipDeviceSynchronize());
+    p->bound = true;
+    return SHIVAE_OK;
+}
+
+int shivae_elbo_step(shivae_plan* p, const float* x, const uint8_t* mask, const float* u, const float* eps, float beta,
+                     float temp, float inv_batch, int flags, float* losses, shivae_stream stream) {
+    SV_REQUIRE(p && x && mask && u && eps && losses, "elbo_step: null argument");
+    if (!p->bound) {
+        set_error("elbo_step: plan has no workspace/parameters bound (call shivae_plan_bind)");
+        return SHIVAE_ERR_UNBOUND;
+    }
+    SV_REQUIRE(temp > 0.f, "elbo_step: temperature must be > 0");
+    return step(p, x, mask, u, eps, beta, temp, inv_batch, flags, losses, static_cast<hipStream_t>(stream));
+}
+
+int shivae_output_width(const shivae_plan* p, int which) {
+    if (!p) return 0;
+    switch (which) {
+        case SHIVAE_O_Z: case SHIVAE_O_Z_MEAN: case SHIVAE_O_Z_STD: case SHIVAE_O_ZP_MEAN: case SHIVAE_O_ZP_STD: return p->Z;
+        case SHIVAE_O_S: case SHIVAE_O_S_PROBS: return p->K;
+        case SHIVAE_O_DEC_PARAMS: return p->P;
+        case SHIVAE_O_ROWLOSS: return 6;
+        case SHIVAE_O_H_PREV: case SHIVAE_O_PHI_Z: return p->H;
+    }
+    return 0;
+}
+
+int shivae_get_output(shivae_plan* p, int which, float* dst, shivae_stream stream) {
+    SV_REQUIRE(p && dst, "get_output: null argument");
+    if (!p->bound) { set_error("get_output: plan not bound"); return SHIVAE_ERR_UNBOUND; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t R = p->R;
+    switch (which) {
+        case SHIVAE_O_Z: return launch_unpad_copy(p->wsf("z"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_Z_MEAN: return launch_unpad_copy(p->wsf("mu"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_Z_STD: return launch_unpad_copy(p->wsf("sd"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_ZP_MEAN: return launch_unpad_copy(p->wsf("mup"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_ZP_STD: return launch_unpad_copy(p->wsf("sdp"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_S: return launch_unpad_copy(p->wsf("emb"), p->Ep, p->Hp, p->K, dst, R, s);
+        case SHIVAE_O_S_PROBS: return launch_unpad_copy(p->wsf("probs"), p->Kp, 0, p->K, dst, R, s);
+        case SHIVAE_O_PHI_Z: return launch_unpad_copy(p->wsf("emb"), p->Ep, 0, p->H, dst, R, s);
+        case SHIVAE_O_H_PREV: return launch_unpad_copy(p->wsf("emb"), p->Ep, p->Hp + p->Kp, p->H, dst, R, s);
+        case SHIVAE_O_ROWLOSS: return launch_unpad_copy(p->wsf("rowloss"), 6, 0, 6, dst, R, s);
+        case SHIVAE_O_DEC_PARAMS:
+            SV_REQUIRE(p->last_flags & SHIVAE_STEP_KEEP_PARAMS, "get_output: last step did not keep decoder parameters");
+            return launch_unpad_copy(p->wsf("pfull"), p->P, 0, p->P, dst, R, s);
+    }
+    set_error("get_output: unknown output %d", which);
+    return SHIVAE_ERR_INVALID;
+}
+
+int shivae_get_persum(shivae_plan* p, float* dst, shivae_stream stream) {
+    SV_REQUIRE(p && dst, "get_persum: null argument");
+    if (!p->bound) { set_error("get_persum: plan not bound"); return SHIVAE_ERR_UNBOUND; }
+    SV_CHECK_HIP(hipMemcpyAsync(dst, p->wsf("persum"), (size_t)p->B * 6 * sizeof(float), hipMemcpyDeviceToDevice,
+                                static_cast<hipStream_t>(stream)));
+    return SHIVAE_OK;
+}
+
+int shivae_heter_nll(shivae_plan* p, const float* x, const uint8_t* mask, const float* params, int ldp, float* dparams,
+                     int rows, float gs, float* rowloss, shivae_stream stream) {
+    SV_REQUIRE(p && x && mask && params && rowloss, "heter_nll: null argument");
+    SV_REQUIRE(ldp >= p->P && rows >= 0, "heter_nll: ldp %d < P %d", ldp, p->P);
+    if (!p->attrs_dev) {
+        SV_TRY(upload(p, p->attrs, &p->attrs_dev));
+    }
+    return launch_heter_nll(p->attrs_dev, p->D, p->learn_std, x, p->X, mask, p->X, params, ldp, dparams, ldp, rows, gs,
+                            rowloss, static_cast<hipStream_t>(stream));
+}
+
+int shivae_kl_terms(const float* mu_q, const float* std_q, const float* mu_p, const float* std_p, int ldz,
+                    const float* s_probs, int ldk, int rows, int Z, int K, float kl_scale, float* dmu_q, float* dstd_q,
+                    float* dmu_p, float* dstd_p_pre, float* dlogits, float* rowloss, shivae_stream stream) {
+    SV_REQUIRE(mu_q && std_q && mu_p && std_p && s_probs && rowloss, "kl_terms: null argument");
+    SV_REQUIRE(Z > 0 && K > 0 && ldz >= Z && ldk >= K && rows >= 0, "kl_terms: bad sizes");
+    const bool any = dmu_q || dstd_q || dmu_p || dstd_p_pre || dlogits;
+    SV_REQUIRE(!any || (dmu_q && dstd_q && dmu_p && dstd_p_pre && dlogits), "kl_terms: pass all gradient outputs or none");
+    return launch_kl(mu_q, std_q, mu_p, std_p, ldz, s_probs, ldk, dmu_q, dstd_q, dmu_p, dstd_p_pre, dlogits, rows, Z, K,
+                     kl_scale, rowloss, static_cast<hipStream_t>(stream));
+}
+
+int shivae_reparam_fwd(const float* logits, const float* u, int ldk, int K, float temp, float* s, float* s_probs,
+                       const float* mean, const float* sd, const float* eps, int ldz, int Z, float* z, int rows,
+                       shivae_stream stream) {
+    SV_REQUIRE(logits && u && s && s_probs && mean && sd && eps && z, "reparam_fwd: null argument");
+    SV_REQUIRE(temp > 0.f && K > 0 && Z > 0 && ldk >= K && ldz >= Z, "reparam_fwd: bad sizes");
+    return launch_reparam_fwd(logits, u, ldk, K, temp, s, s_probs, mean, sd, eps, ldz, Z, z, rows,
+                              static_cast<hipStream_t>(stream));
+}
+
+int shivae_reparam_bwd(const float* s, const float* ds, int ldk, int K, float temp, float* dlogits, const float* eps,
+                       const float* dz, int ldz, int Z, float* dmean, float* dstd, int rows, shivae_stream stream) {
+    SV_REQUIRE(s && ds && dlogits && eps && dz && dmean && dstd, "reparam_bwd: null argument");
+    SV_REQUIRE(temp > 0.f && K > 0 && Z > 0 && ldk >= K && ldz >= Z, "reparam_bwd: bad sizes");
+    return launch_reparam_bwd(s, ds, ldk, K, temp, dlogits, eps, dz, ldz, Z, dmean, dstd, rows,
+                              static_cast<hipStream_t>(stream));
+}
+
+int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* aux, int ldaux, int epi, int splitk, shivae_stream stream) {
+    SV_REQUIRE(A && B && C, "gemm: null operand");
+    SV_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+    SV_REQUIRE(!(epi & EPI_BIAS) || bias, "gemm: bias epilogue without bias");
+    SV_REQUIRE(!(epi & EPI_MASK) || aux, "gemm: mask epilogue without aux");
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0};
+    GemmGroup g{A, B, C, bias, aux};
+    return launch_gemm(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
+}
+
+int shivae_zero(float* buf, int64_t n, shivae_stream stream) {
+    SV_REQUIRE(buf && n >= 0, "zero: bad argument");
+    SV_CHECK_HIP(hipMemsetAsync(buf, 0, (size_t)n * sizeof(float), static_cast<hipStream_t>(stream)));
+    return SHIVAE_OK;
+}
+
+int shivae_sqnorm(const float* buf, int64_t n, float* scratch, float* out, shivae_stream stream) {
+    SV_REQUIRE(buf && scratch && out && n >= 0, "sqnorm: bad argument");
+    return launch_sqnorm(buf, n, scratch, out, static_cast<hipStream_t>(stream));
+}
+
+int shivae_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sqnorm, float clip,
+                     float lr, float b1, float b2, float eps, int step, shivae_stream stream) {
+    SV_REQUIRE(params && grads && m && v && sqnorm, "clip_adam: null argument");
+    return launch_clip_adam(params, grads, m, v, n, sqnorm, clip, lr, b1, b2, eps, step, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

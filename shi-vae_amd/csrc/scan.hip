@@ -1,0 +1,551 @@
+// Fused, time-looped recurrent cell of the Shi-VAE (north_star kernels 1, 2 and 4).
+//
+// Reference: shivae.py:102-143 (the per-timestep loop), encoders.py:70-98 (GMEncoder.forward),
+// samplers.py:23-62 (Gumbel-softmax / Gaussian reparameterisation), shivae.py:132-137 (phi_z, nn.LSTM
+// single step).  Everything that does NOT depend on h_{t-1} has been hoisted into batched GEMMs
+// (gemm.hip); what is left here is the strictly serial chain
+//     h_{t-1} -> a_s -> s logits -> (Gumbel) s_t -> e1 -> e2 -> (mu, std) -> z_t -> phi_z -> LSTM -> h_t
+// and, in the backward kernel, the same chain in reverse time (full BPTT: the reference never
+// detaches h/c between its 50-step chunks, shivae.py:102-137).
+//
+// One workgroup owns a tile of 16 sequences and loops over all T steps; nothing is exchanged
+// between workgroups.  Formulation: activations are kept TRANSPOSED, [feature][16 sequences], so a
+// layer is  out[N,16] = W[N,Kin] * in[Kin,16]  on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A
+// operand and the activations as the B operand.  Consequences:
+//   * weights are pre-packed (pack kernels below) in exact A-operand order: one MFMA's 64 weights
+//     are 256 contiguous bytes, a lane's float4 feeds four consecutive MFMAs;
+//   * the D layout (row = 4*(lane>>4)+r, col = lane&15) of one layer's output tile nt is exactly the
+//     B-operand float4 of k-block nt of the next layer, so activations move between layers as one
+//     ds_write_b128 / ds_read_b128 per lane in a "quad-interleaved" LDS image
+//         idx(k, j) = ((k>>2)*16 + j)*4 + (k&3)          (conflict-free for both),
+//   * the LSTM cell state c and the running dh/dc of the backward pass never leave registers: the
+//     wave that owns hidden units [16*ht, 16*ht+16) computes all four gates of those units.
+// Feature dims are padded to multiples of 16 (H->Hp, Z->Zp, K->Kp) with zero weights/biases, which
+// keeps every padded lane at exactly 0 through ReLU, the LSTM cell (c=0 -> h=0) and the gradients.
+#include "cell_math.h"
+#include "common.h"
+
+namespace shivae {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int qidx(int tile, int q, int j) { return ((tile * 4 + q) * 16 + j) * 4; }
+
+// acc[a] += Wp(tile nt[a]) * in, summed over KB k-blocks of 16
+template <int NA>
+__device__ __forceinline__ void mma_acc(f32x4 (&acc)[NA], const float* __restrict__ W, int KB, const int (&nt)[NA],
+                                        const float* in, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+
+    for (int kb = 0; kb < KB; ++kb) {
+        const float4 b = *reinterpret_cast<const float4*>(in + qidx(kb, q, j));
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const float4 w = *reinterpret_cast<const float4*>(W + ((size_t)(nt[a] * KB + kb) * 64 + lane) * 4);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, acc[a], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, acc[a], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, acc[a], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, acc[a], 0, 0, 0);
+        }
+    }
+}
+
+struct Src {
+    const float* W;
+    const float* in;
+    int KB;
+};
+
+// out tiles 0..ntiles-1 are dealt round-robin to the waves; epi(nt, acc) gets the finished tile
+template <int NSRC, class Epi>
+__device__ __forceinline__ void layer(int ntiles, const Src (&src)[NSRC], int wid, int NW, int lane, Epi epi) {
+    int t0 = wid;
+    for (; t0 + 3 * NW < ntiles; t0 += 4 * NW) {
+        const int nt[4] = {t0, t0 + NW, t0 + 2 * NW, t0 + 3 * NW};
+        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) mma_acc<4>(acc, src[s].W, src[s].KB, nt, src[s].in, lane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) epi(nt[a], acc[a]);
+    }
+    for (; t0 < ntiles; t0 += NW) {
+        const int nt[1] = {t0};
+        f32x4 acc[1] = {{0, 0, 0, 0}};
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) mma_acc<1>(acc, src[s].W, src[s].KB, nt, src[s].in, lane);
+        epi(t0, acc[0]);
+    }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+__device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0.f ? v[0] : 0.f, a[1] > 0.f ? v[1] : 0.f, a[2] > 0.f ? v[2] : 0.f, a[3] > 0.f ? v[3] : 0.f}; }
+
+// ---------------------------------------------------------------------------------- forward
+template <int MAXS>
+__global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int Hp = a.Hp, Zp = a.Zp, Kp = a.Kp, Ep = a.Ep, B = a.B;
+    const int HT = Hp >> 4, ZT = Zp >> 4, KT = Kp >> 4;
+    const int bj = blockIdx.x * 16 + j;
+    const bool live = bj < B;
+    float* hb0 = smem;
+    float* hb1 = hb0 + Hp * 16;
+    float* bufA = hb1 + Hp * 16;
+    float* bufB = bufA + Hp * 16;
+    float* sbuf = bufB + Hp * 16;
+    float* lgbuf = sbuf + Kp * 16;
+    float* zbuf = lgbuf + Kp * 16;
+    const float* Wb = a.wpack;
+
+    for (int i = tid; i < Hp * 16; i += blockDim.x) hb0[i] = 0.f;  // shivae.py:93 h0 = 0
+    f32x4 creg[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) creg[s] = f32x4{0, 0, 0, 0};  // shivae.py:94 c0 = 0
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const size_t row = (size_t)t * B + (live ? bj : 0);
+        const float* h = cur ? hb1 : hb0;
+        float* hn = cur ? hb0 : hb1;
+
+        // S1: a_s = relu(xs_pre + Wxs0[:, X:] h)          encoders.py:83 (x half hoisted)
+        {
+            const Src src[1] = {{Wb + a.w.xsh, h, HT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                if (live) v += ld4(a.xs_pre + row * Hp + n);
+                v = relu4(v);
+                st4(bufA + qidx(nt, q, j), v);
+                if (live) st4(a.as_ + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // S2: s logits = LeakyReLU(Wxs2 a_s + b)           encoders.py:56-57
+        {
+            const Src src[1] = {{Wb + a.w.lg, bufA, HT}};
+            layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                v += ld4(Wb + a.w.b_lg + nt * 16 + 4 * q);
+                st4(lgbuf + qidx(nt, q, j), f32x4{sv_leaky(v[0]), sv_leaky(v[1]), sv_leaky(v[2]), sv_leaky(v[3])});
+            });
+        }
+        __syncthreads();
+        // S3: s_probs = softmax(logits); s = softmax((logits + gumbel(u)) / temp)   encoders.py:87-88
+        if (tid < 16) {
+            const int jj = tid, bb = blockIdx.x * 16 + jj;
+            const bool lv = bb < B;
+            const size_t r = (size_t)t * B + (lv ? bb : 0);
+            float m1 = -INFINITY, m2 = -INFINITY;
+            for (int k = 0; k < a.K; ++k) {
+                const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                m1 = fmaxf(m1, l);
+                m2 = fmaxf(m2, (l + sv_gumbel(u)) / a.temp);
+            }
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < a.K; ++k) {
+                const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                s1 += expf(l - m1);
+                s2 += expf((l + sv_gumbel(u)) / a.temp - m2);
+            }
+            for (int k = 0; k < Kp; ++k) {
+                float sv = 0.f;
+                if (k < a.K) {
+                    const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                    const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                    sv = expf((l + sv_gumbel(u)) / a.temp - m2) / s2;
+                    if (lv) {
+                        a.logits[r * Kp + k] = l;
+                        a.probs[r * Kp + k] = expf(l - m1) / s1;
+                        a.emb[r * Ep + Hp + k] = sv;
+                    }
+                }
+                sbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = sv;
+            }
+        }
+        __syncthreads();
+        // S4: e1 = relu(ex_pre + We0[:, H:H+K] s + We0[:, H+K:] h)    encoders.py:91 (phi_x part hoisted)
+        {
+            const Src src[2] = {{Wb + a.w.e0s, sbuf, KT}, {Wb + a.w.e0h, h, HT}};
+            layer<2>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                if (live) v += ld4(a.ex_pre + row * Hp + n);
+                v = relu4(v);
+                st4(bufB + qidx(nt, q, j), v);
+                if (live) st4(a.e1 + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // S5: e2 = relu(We2 e1 + b)                         encoders.py:63-64
+        {
+            const Src src[1] = {{Wb + a.w.e2, bufB, HT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                v = relu4(v + ld4(Wb + a.w.b_e2 + n));
+                st4(bufA + qidx(nt, q, j), v);
+                if (live) st4(a.e2 + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // S6: mu, std = softplus(.), z = eps*std + mu       encoders.py:93-96, samplers.py:57-62
+        for (int zt = wid; zt < ZT; zt += NW) {
+            const int nt[1] = {zt};
+            f32x4 am[1] = {{0, 0, 0, 0}}, as[1] = {{0, 0, 0, 0}};
+            mma_acc<1>(am, Wb + a.w.mu, HT, nt, bufA, lane);
+            mma_acc<1>(as, Wb + a.w.sd, HT, nt, bufA, lane);
+            const int n = zt * 16 + 4 * q;
+            const f32x4 mu = am[0] + ld4(Wb + a.w.b_mu + n);
+            const f32x4 sp = as[0] + ld4(Wb + a.w.b_sd + n);
+            f32x4 sd, z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sd[r] = sv_softplus(sp[r]);
+                const float e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
+                z[r] = e * sd[r] + mu[r];
+            }
+            st4(zbuf + qidx(zt, q, j), z);
+            if (live) {
+                st4(a.mu + row * Zp + n, mu);
+                st4(a.sd + row * Zp + n, sd);
+                st4(a.z + row * Zp + n, z);
+            }
+        }
+        __syncthreads();
+        // S7: phi_z = relu(Wz z + b)                        shivae.py:132
+        {
+            const Src src[1] = {{Wb + a.w.pz, zbuf, ZT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                v = relu4(v + ld4(Wb + a.w.b_pz + n));
+                st4(bufB + qidx(nt, q, j), v);
+                if (live) st4(a.emb + row * Ep + n, v);
+            });
+        }
+        __syncthreads();
+        // S8: LSTM cell (gate order i,f,g,o), c in registers  shivae.py:136
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int ht = wid + s * NW;
+            if (ht < HT) {
+                const int nt[4] = {ht, HT + ht, 2 * HT + ht, 3 * HT + ht};
+                f32x4 g4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                mma_acc<4>(g4, Wb + a.w.ih, HT, nt, bufB, lane);
+                mma_acc<4>(g4, Wb + a.w.hh, HT, nt, h, lane);
+                const int n = ht * 16 + 4 * q;
+#pragma unroll
+                for (int gidx = 0; gidx < 4; ++gidx) g4[gidx] += ld4(Wb + a.w.b_g + gidx * Hp + n);
+                f32x4 gi, gf, gg, go, cn, hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gi[r] = sv_sigmoid(g4[0][r]);
+                    gf[r] = sv_sigmoid(g4[1][r]);
+                    gg[r] = tanhf(g4[2][r]);
+                    go[r] = sv_sigmoid(g4[3][r]);
+                    cn[r] = gf[r] * creg[s][r] + gi[r] * gg[r];
+                    hv[r] = go[r] * tanhf(cn[r]);
+                }
+                creg[s] = cn;
+                st4(hn + qidx(ht, q, j), hv);
+                if (live) {
+                    float* gp = a.gates + row * 4 * Hp + n;
+                    st4(gp, gi); st4(gp + Hp, gf); st4(gp + 2 * Hp, gg); st4(gp + 3 * Hp, go);
+                    st4(a.cnew + row * Hp + n, cn);
+                    if (t + 1 < a.T) st4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
+                    else if (a.h_last) st4(a.h_last + (size_t)bj * Hp + n, hv);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- backward
+template <int MAXS>
+__global__ __launch_bounds__(256) void scan_bwd_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int Hp = a.Hp, Zp = a.Zp, Kp = a.Kp, Ep = a.Ep, B = a.B;
+    const int HT = Hp >> 4, ZT = Zp >> 4, KT = Kp >> 4;
+    const int bj = blockIdx.x * 16 + j;
+    const bool live = bj < B;
+    float* dhb = smem;
+    float* dgb = dhb + Hp * 16;
+    float* bufA = dgb + 4 * Hp * 16;
+    float* bufB = bufA + Hp * 16;
+    float* dmub = bufB + Hp * 16;
+    float* dsdb = dmub + Zp * 16;
+    float* dsb = dsdb + Zp * 16;
+    float* dlgb = dsb + Kp * 16;
+    const float* Wb = a.wpack;
+    const f32x4 zero4 = {0, 0, 0, 0};
+
+    for (int i = tid; i < Hp * 16; i += blockDim.x) dhb[i] = 0.f;
+    f32x4 dcreg[MAXS], dhacc[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) dcreg[s] = zero4;
+    __syncthreads();
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t row = (size_t)t * B + (live ? bj : 0);
+        // B1: LSTM cell backward on the owned hidden units (elementwise, registers)
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int ht = wid + s * NW;
+            dhacc[s] = zero4;
+            if (ht < HT) {
+                const int n = ht * 16 + 4 * q;
+                const f32x4 dh = ld4(dhb + qidx(ht, q, j));
+                f32x4 gi = zero4, gf = zero4, gg = zero4, go = zero4, cn = zero4, cp = zero4;
+                if (live) {
+                    const float* gp = a.gates + row * 4 * Hp + n;
+                    gi = ld4(gp); gf = ld4(gp + Hp); gg = ld4(gp + 2 * Hp); go = ld4(gp + 3 * Hp);
+                    cn = ld4(a.cnew + row * Hp + n);
+                    if (t > 0) cp = ld4(a.cnew + (row - B) * Hp + n);
+                }
+                f32x4 di, df, dg, dO, dc = dcreg[s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tc = tanhf(cn[r]);
+                    const float dct = dc[r] + dh[r] * go[r] * (1.f - tc * tc);
+                    di[r] = dct * gg[r] * gi[r] * (1.f - gi[r]);
+                    df[r] = dct * cp[r] * gf[r] * (1.f - gf[r]);
+                    dg[r] = dct * gi[r] * (1.f - gg[r] * gg[r]);
+                    dO[r] = dh[r] * tc * go[r] * (1.f - go[r]);
+                    dc[r] = dct * gf[r];
+                }
+                dcreg[s] = dc;
+                st4(dgb + qidx(ht, q, j), di);
+                st4(dgb + qidx(HT + ht, q, j), df);
+                st4(dgb + qidx(2 * HT + ht, q, j), dg);
+                st4(dgb + qidx(3 * HT + ht, q, j), dO);
+                if (live) {
+                    float* gp = a.d_gates + row * 4 * Hp + n;
+                    st4(gp, di); st4(gp + Hp, df); st4(gp + 2 * Hp, dg); st4(gp + 3 * Hp, dO);
+                }
+            }
+        }
+        __syncthreads();
+        // B2: dphi_z = Wih^T dgates + (decoder's dphi_z); through ReLU.   dh_prev += Whh^T dgates
+        {
+            const Src src[1] = {{Wb + a.w.t_ih, dgb, 4 * HT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                f32x4 pz = zero4;
+                if (live) { v += ld4(a.d_emb + row * Ep + n); pz = ld4(a.emb + row * Ep + n); }
+                v = gate4(v, pz);
+                st4(bufB + qidx(nt, q, j), v);
+                if (live) st4(a.d_phiz_pre + row * Hp + n, v);
+            });
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                const int ht = wid + s * NW;
+                if (ht < HT) {
+                    const int nt[1] = {ht};
+                    f32x4 acc[1] = {dhacc[s]};
+                    mma_acc<1>(acc, Wb + a.w.t_hh, 4 * HT, nt, dgb, lane);
+                    dhacc[s] = acc[0];
+                }
+            }
+        }
+        __syncthreads();
+        // B3: dz = Wz^T dphi_z_pre; dmu = dz + dKL/dmu; dstd_pre = (dz*eps + dKL/dstd) * softplus'
+        for (int zt = wid; zt < ZT; zt += NW) {
+            const int nt[1] = {zt};
+            f32x4 acc[1] = {zero4};
+            mma_acc<1>(acc, Wb + a.w.t_pz, HT, nt, bufB, lane);
+            const int n = zt * 16 + 4 * q;
+            f32x4 dmu = acc[0], dsd = zero4;
+            if (live) {
+                dmu += ld4(a.dmu_ext + row * Zp + n);
+                const f32x4 de = ld4(a.dsd_ext + row * Zp + n), sd = ld4(a.sd + row * Zp + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
+                    dsd[r] = (acc[0][r] * e + de[r]) * sv_softplus_grad_from_out(sd[r]);
+                }
+            }
+            st4(dmub + qidx(zt, q, j), dmu);
+            st4(dsdb + qidx(zt, q, j), dsd);
+            if (live) {
+                st4(a.d_mu + row * Zp + n, dmu);
+                st4(a.d_sd_pre + row * Zp + n, dsd);
+            }
+        }
+        __syncthreads();
+        // B4: de2 = Wm^T dmu + Ws^T dstd_pre, through ReLU
+        {
+            const Src src[2] = {{Wb + a.w.t_mu, dmub, ZT}, {Wb + a.w.t_sd, dsdb, ZT}};
+            layer<2>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                v = gate4(v, live ? ld4(a.e2 + row * Hp + n) : zero4);
+                st4(bufA + qidx(nt, q, j), v);
+                if (live) st4(a.d_e2_pre + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // B5: de1 = We2^T de2_pre, through ReLU
+        {
+            const Src src[1] = {{Wb + a.w.t_e2, bufA, HT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                v = gate4(v, live ? ld4(a.e1 + row * Hp + n) : zero4);
+                st4(bufB + qidx(nt, q, j), v);
+                if (live) st4(a.d_e1_pre + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // B6: ds = We0_s^T de1_pre + (decoder/prior ds);   dh_prev += We0_h^T de1_pre
+        {
+            const Src src[1] = {{Wb + a.w.t_e0s, bufB, HT}};
+            layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                if (live) v += ld4(a.d_emb + row * Ep + Hp + nt * 16 + 4 * q);
+                st4(dsb + qidx(nt, q, j), v);
+            });
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                const int ht = wid + s * NW;
+                if (ht < HT) {
+                    const int nt[1] = {ht};
+                    f32x4 acc[1] = {dhacc[s]};
+                    mma_acc<1>(acc, Wb + a.w.t_e0h, HT, nt, bufB, lane);
+                    dhacc[s] = acc[0];
+                }
+            }
+        }
+        __syncthreads();
+        // B6b: Gumbel-softmax backward + KL(s) gradient, through LeakyReLU
+        if (tid < 16) {
+            const int jj = tid, bb = blockIdx.x * 16 + jj;
+            const bool lv = bb < B;
+            const size_t r = (size_t)t * B + (lv ? bb : 0);
+            float dot = 0.f;
+            for (int k = 0; k < a.K; ++k)
+                dot += (lv ? a.emb[r * Ep + Hp + k] : 0.f) * dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+            for (int k = 0; k < Kp; ++k) {
+                float dl = 0.f;
+                if (k < a.K && lv) {
+                    const float sv = a.emb[r * Ep + Hp + k];
+                    const float ds = dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                    dl = sv * (ds - dot) / a.temp + a.dlg_kl[r * Kp + k];
+                    dl *= a.logits[r * Kp + k] > 0.f ? 1.f : 0.01f;
+                    a.d_lg_pre[r * Kp + k] = dl;
+                }
+                dlgb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = dl;
+            }
+        }
+        __syncthreads();
+        // B7: da_s = Wxs2^T dlogits_pre, through ReLU
+        {
+            const Src src[1] = {{Wb + a.w.t_lg, dlgb, KT}};
+            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                const int n = nt * 16 + 4 * q;
+                v = gate4(v, live ? ld4(a.as_ + row * Hp + n) : zero4);
+                st4(bufA + qidx(nt, q, j), v);
+                if (live) st4(a.d_as_pre + row * Hp + n, v);
+            });
+        }
+        __syncthreads();
+        // B8: dh_{t-1} = Whh^T.. + We0_h^T.. + Wxs0_h^T das_pre + (decoder/prior dh_prev)
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int ht = wid + s * NW;
+            if (ht < HT) {
+                const int nt[1] = {ht};
+                f32x4 acc[1] = {dhacc[s]};
+                mma_acc<1>(acc, Wb + a.w.t_xsh, HT, nt, bufA, lane);
+                if (live) acc[0] += ld4(a.d_emb + row * Ep + Hp + Kp + ht * 16 + 4 * q);
+                st4(dhb + qidx(ht, q, j), acc[0]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------- packing
+__global__ void pack_weights_kernel(const PackJob* jobs, float* dst_base) {
+    const PackJob jb = jobs[blockIdx.y];
+    const int KB = jb.Ip >> 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < jb.Op * jb.Ip; e += gridDim.x * blockDim.x) {
+        // e enumerates the PACKED order: (((nt*KB + kb)*64 + lane)*4 + c)
+        const int c = e & 3, ln = (e >> 2) & 63, blk = e >> 8;
+        const int kb = blk % KB, nt = blk / KB;
+        const int o = nt * 16 + (ln & 15), i = kb * 16 + (ln >> 4) * 4 + c;
+        const int ob = o / jb.oblk_pad, orr = o % jb.oblk_pad, ib = i / jb.iblk_pad, irr = i % jb.iblk_pad;
+        float v = 0.f;
+        if (orr < jb.oblk_true && irr < jb.iblk_true) {
+            const int so = ob * jb.oblk_true + orr, si = ib * jb.iblk_true + irr;
+            v = jb.transposed ? jb.src[(size_t)si * jb.ld + so] : jb.src[(size_t)so * jb.ld + si];
+        }
+        dst_base[jb.dst_off + e] = v;
+    }
+}
+
+__global__ void pack_bias_kernel(const PackJob* jobs, float* dst_base) {
+    const PackJob jb = jobs[blockIdx.y];
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.Op; o += gridDim.x * blockDim.x) {
+        const int ob = o / jb.oblk_pad, orr = o % jb.oblk_pad;
+        float v = 0.f;
+        if (orr < jb.oblk_true) {
+            const int so = ob * jb.oblk_true + orr;
+            v = jb.src[so] + (jb.src2 ? jb.src2[so] : 0.f);
+        }
+        dst_base[jb.dst_off + o] = v;
+    }
+}
+
+int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int nb, float* dst, hipStream_t stream) {
+    if (nw > 0) hipLaunchKernelGGL(pack_weights_kernel, dim3(64, nw), dim3(256), 0, stream, wjobs_dev, dst);
+    if (nb > 0) hipLaunchKernelGGL(pack_bias_kernel, dim3(4, nb), dim3(256), 0, stream, bjobs_dev, dst);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------- launch
+static int scan_geometry(const ScanArgs& a, int& nw, int& maxs) {
+    const int HT = a.Hp / 16;
+    nw = HT >= 4 ? 4 : (HT >= 2 ? 2 : 1);
+    const int need = ceil_div(HT, nw);
+    maxs = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    SV_REQUIRE(need <= 8, "scan: h_dim %d too large for the register-resident cell (max 512)", a.H);
+    return SHIVAE_OK;
+}
+
+size_t scan_fwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (4 * a.Hp + 2 * a.Kp + a.Zp); }
+size_t scan_bwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (7 * a.Hp + 2 * a.Kp + 2 * a.Zp); }
+
+template <int MAXS>
+static int launch_scan_t(const ScanArgs& a, bool bwd, int nw, hipStream_t stream) {
+    const size_t lds = bwd ? scan_bwd_lds_bytes(a) : scan_fwd_lds_bytes(a);
+    SV_REQUIRE(lds <= 160 * 1024, "scan: needs %zu B of LDS (> 160 KiB)", lds);
+    auto kern = bwd ? scan_bwd_kernel<MAXS> : scan_fwd_kernel<MAXS>;
+    if (lds > 64 * 1024)
+        SV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.B, 16)), dim3(nw * 64), lds, stream, a);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream) {
+    if (a.T <= 0 || a.B <= 0) return SHIVAE_OK;
+    int nw, maxs;
+    SV_TRY(scan_geometry(a, nw, maxs));
+    switch (maxs) {
+        case 1: return launch_scan_t<1>(a, bwd, nw, stream);
+        case 2: return launch_scan_t<2>(a, bwd, nw, stream);
+        case 4: return launch_scan_t<4>(a, bwd, nw, stream);
+        default: return launch_scan_t<8>(a, bwd, nw, stream);
+    }
+}
+
+}  // namespace shivae
