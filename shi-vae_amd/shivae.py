@@ -1,0 +1,518 @@
+"""Shi-VAE model with the reference's construction / forward / imputation API, running its train
+step on the hand-written HIP kernels of libshivae_hip.so.
+
+Mirrors ``src/models/shivae.py`` (ShiVAE) and ``src/models/base_missvae.py`` (BaseMissVAE):
+same constructor, ``model(x, mask, beta, temp) -> loss dict``, ``feed2model``, ``compute_loss``,
+``heter_nll``, ``kl_q_z``, ``kl_q_s``, ``reconstruction``, ``generate_heter_samples`` and the same
+``state_dict`` keys, so reference checkpoints load and ``torch.optim.Adam(model.parameters())``
+works.  PyTorch is used for device memory, streams and torch.distributed only; there is no eager
+fallback: without the HIP library (or without a GPU) the step raises.
+
+Differences that are deliberate (and documented in DESIGN.md):
+  * all parameters are views into ONE flat fp32 buffer (and gradients into one flat buffer), laid
+    out by the native plan so that per-attribute decoder weights are stacked for grouped GEMMs;
+  * forward+backward are fused: ``model(...)`` in training mode already computes the gradients,
+    ``loss['n_elbo'].backward()`` publishes them to ``p.grad``;
+  * noise is explicit.  By default it is drawn on the device (``noise_mode='device'``);
+    ``noise_mode='reference'`` replays the reference's CPU stream (torch.rand(B,K) then normal_(B,Z)
+    per timestep, samplers.py:25,60) so that ``torch.manual_seed`` reproduces the reference exactly;
+    ``set_noise(u, eps)`` injects tensors for the next call.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from . import utils
+
+print_shivae = "ELBO:{n_elbo:.3f} | NLL:{nll_loss:.3f}  KL_Q_Z:{kld_q_z:.3f}  KL_Q_S:{kld_q_s:.3f}|  " \
+               "Real:{nll_real:.3f}  Pos:{nll_pos:.3f}  Bin:{nll_bin:.3f}  Cat:{nll_cat:.3f}"
+LOSSES = ["real", "pos", "bin", "cat"]
+LOSS_KEYS = ["n_elbo", "nll_loss", "kld", "kld_q_z", "kld_q_s", "nll_real", "nll_pos", "nll_bin", "nll_cat"]
+FIXED_STD = 0.1  # decoders.py:22
+
+
+def set_device():
+    """lib/aux.py:37-47."""
+    return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+class _Holder(nn.Module):
+    """Plain container; only gives parameters their reference names."""
+
+
+class _AttachGrads(torch.autograd.Function):
+    """Gives n_elbo a grad_fn.  The gradients were already computed by the fused step; backward
+    publishes them to ``p.grad`` (scaled by the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, hook, value, model):
+        ctx.model = model
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        ctx.model._publish_grads(go)
+        return None, None, None
+
+
+class ShiVAE(nn.Module):
+    def __init__(self, h_dim, z_dim, s_dim, n_layers, types_list=None, learn_std=False, activation_layer='ReLU',
+                 gain_init=1, device=None):
+        super().__init__()
+        assert types_list is not None  # base_missvae.py:41
+        if str(activation_layer).lower() != 'relu':
+            raise NotImplementedError("the HIP Shi-VAE step implements activation_layer='ReLU' (the reference default)")
+        if int(n_layers) != 1:
+            raise NotImplementedError("the HIP Shi-VAE step implements n_layers=1 (the reference's setting)")
+        self.types_list = utils.reindex_types_list(types_list)
+        self.transform_idx = utils.get_idx_transform(self.types_list)
+        self.device = device or set_device()
+        self.learn_std = bool(learn_std)
+        self.K = 1  # IWAE / Monte-Carlo replication factors of the reference (always 1 there)
+        self.M = 1
+        self.x_dim = utils.get_x_dim(self.types_list)
+        self.h_dim, self.z_dim, self.s_dim, self.n_layers = int(h_dim), int(z_dim), int(s_dim), 1
+
+        self.noise_mode = 'device'
+        self.print_losses = False   # the reference prints one line per forward (base_missvae.py:163)
+        self.check_nan = True       # base_missvae.py:223-228 (one host sync per forward)
+        self.workspace_limit_bytes = int(float(os.environ.get("SHIVAE_WS_GB", "0")) * 1e9) or None
+        self.chunk_rows = int(os.environ.get("SHIVAE_CHUNK_ROWS", "0"))
+        self._pending_noise = None
+        self._plans = {}
+        self._active = None
+        self._workspace = None
+        self._last = None
+
+        self._attr_types = [N.TYPE_CODE[t['type']] for t in self.types_list]
+        self._attr_ncls = [int(t['dim']) if t['type'] == 'cat' else 1 for t in self.types_list]
+        for t in self.types_list:
+            if t['type'] == 'cat':
+                assert int(t['dim']) == int(t['nclass']), "categorical dim must equal nclass"
+        self._layout = N.Plan(1, 1, self.h_dim, self.z_dim, self.s_dim, self._attr_types, self._attr_ncls,
+                              self.learn_std)
+        self.p_dim = self._layout.p_dim
+        self._n_flat = self._layout.num_params
+        dev = torch.device(self.device)
+        self._flat = torch.zeros(self._n_flat, dtype=torch.float32, device=dev)
+        self._gflat = torch.zeros(self._n_flat, dtype=torch.float32, device=dev)
+        self._hook = torch.zeros(1, device=dev, requires_grad=True)
+        self._slices = []  # (parameter, offset, numel, shape) in registration order
+        self._build_parameters()
+        self.init_weights(gain=gain_init)
+
+    # ------------------------------------------------------------------ parameters
+    def _register(self, holder, pname, tensor_id, attr=0, bias=False, row=None):
+        info = self._layout.param_info(tensor_id, attr)
+        assert info is not None, (pname, tensor_id, attr)
+        off, r, c = info
+        shape = (c,) if bias else (r, c)
+        n = r * c
+        p = nn.Parameter(self._flat[off:off + n].view(shape))
+        holder.register_parameter(pname, p)
+        self._slices.append((p, off, n, shape))
+
+    def _linear(self, parent, name, wid, attr=0):
+        h = _Holder()
+        parent.add_module(name, h)
+        self._register(h, "weight", wid, attr)
+        self._register(h, "bias", wid + 1, attr, bias=True)
+        return h
+
+    def _build_parameters(self):
+        """Same module tree / registration order as shivae.py:48-68, encoders.py:47-68, decoders.py:54-107."""
+        P = N.P
+        enc = _Holder(); self.add_module("encoder", enc)
+        for name, ids in (("phi_x", ((0, P["PHIX0_W"]), (2, P["PHIX2_W"]))), ("phi_x_s", ((0, P["XS0_W"]), (2, P["XS2_W"]))),
+                          ("enc", ((0, P["E0_W"]), (2, P["E2_W"])))):
+            seq = _Holder(); enc.add_module(name, seq)
+            for idx, wid in ids:
+                self._linear(seq, str(idx), wid)
+        self._linear(enc, "enc_mean", P["ENCMEAN_W"])
+        seq = _Holder(); enc.add_module("enc_std", seq); self._linear(seq, "0", P["ENCSTD_W"])
+        seq = _Holder(); self.add_module("phi_z", seq); self._linear(seq, "0", P["PHIZ_W"])
+        seq = _Holder(); self.add_module("prior", seq); self._linear(seq, "0", P["PRIOR0_W"])
+        self._linear(self, "prior_mean", P["PRIORMEAN_W"])
+        seq = _Holder(); self.add_module("prior_std", seq); self._linear(seq, "0", P["PRIORSTD_W"])
+        dec = _Holder(); self.add_module("dec", dec)
+        dd = _Holder(); dec.add_module("decoder_dict", dd)
+        for d, t in enumerate(self.types_list):
+            v = _Holder(); dd.add_module(t['name'], v)
+            trunk = _Holder(); v.add_module("dec", trunk)
+            self._linear(trunk, "0", P["DEC0_W"], d)
+            self._linear(trunk, "2", P["DEC2_W"], d)
+            self._linear(trunk, "4", P["DEC4_W"], d)
+            ty = t['type']
+            if ty in ('real', 'pos'):
+                self._linear(v, "dec_mean", P["HEADMEAN_W"], d)
+                if self.learn_std:
+                    s = _Holder(); v.add_module("dec_std", s); self._linear(s, "0", P["HEADSTD_W"], d)
+            else:
+                s = _Holder(); v.add_module("dec_p" if ty == 'bin' else "dec_p_cat", s)
+                self._linear(s, "0", P["HEAD0_W"], d)
+                self._linear(s, "2", P["HEADOUT_W"], d)
+        rnn = _Holder(); self.add_module("rnn", rnn)
+        self._register(rnn, "weight_ih_l0", P["RNN_WIH"])
+        self._register(rnn, "weight_hh_l0", P["RNN_WHH"])
+        self._register(rnn, "bias_ih_l0", P["RNN_BIH"], bias=True)
+        self._register(rnn, "bias_hh_l0", P["RNN_BHH"], bias=True)
+
+    def init_weights(self, gain=1):
+        """base_missvae.py:63-85: LSTM weights orthogonal, other weights Xavier-normal, biases 0."""
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if 'bias' in name:
+                    nn.init.constant_(p, 0.0)
+                elif name.startswith('rnn.'):
+                    nn.init.orthogonal_(p, gain=gain)
+                else:
+                    nn.init.xavier_normal_(p, gain=gain)
+
+    def get_name(self):
+        return self.__class__.__name__
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._reflatten()
+        return self
+
+    def _reflatten(self):
+        """After .to()/.cuda() the parameters are separate tensors again: re-pack them into one buffer."""
+        if not self._slices:
+            return
+        dev = self._slices[0][0].device
+        if self._slices[0][0].data_ptr() == self._flat.data_ptr() + 4 * self._slices[0][1] and self._flat.device == dev:
+            return
+        flat = torch.zeros(self._n_flat, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off, n, shape in self._slices:
+                flat[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat[off:off + n].view(shape)
+                p.grad = None
+        self._flat = flat
+        self._gflat = torch.zeros_like(flat)
+        self._hook = torch.zeros(1, device=dev, requires_grad=True)
+        self.device = dev.type
+        self._plans, self._active, self._workspace = {}, None, None
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        return self._gflat
+
+    def zero_grad(self, set_to_none=True):
+        self._gflat.zero_()
+        if set_to_none:
+            for p, _, _, _ in self._slices:
+                p.grad = None
+
+    def _publish_grads(self, go=None):
+        fresh = self._slices[0][0].grad is None
+        if go is not None and fresh:
+            self._gflat.mul_(go.reshape(()))
+        for p, off, n, shape in self._slices:
+            g = self._gflat[off:off + n].view(shape)
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)
+
+    # ------------------------------------------------------------------ plans / workspace
+    def _require_gpu(self):
+        if self._flat.device.type != 'cuda':
+            raise N.ShiVAENativeError("the Shi-VAE step runs only on a GPU (HIP kernels); model is on %s and there "
+                                      "is no CPU fallback" % self._flat.device)
+        N.lib()
+
+    def _make_plan(self, T, B):
+        key = (T, B)
+        if key not in self._plans:
+            self._plans[key] = N.Plan(T, B, self.h_dim, self.z_dim, self.s_dim, self._attr_types, self._attr_ncls,
+                                      self.learn_std, self.chunk_rows)
+        return self._plans[key]
+
+    def _budget(self):
+        if self.workspace_limit_bytes:
+            return self.workspace_limit_bytes
+        free, _ = torch.cuda.mem_get_info(self._flat.device)
+        held = self._workspace.numel() if self._workspace is not None else 0
+        return int((free + held) * 0.85)
+
+    def micro_batch(self, T, B):
+        """Largest per-call batch whose workspace fits the budget (callers' B is split into these)."""
+        budget = self._budget()
+        bm = B
+        while True:
+            ws = self._make_plan(T, bm).workspace_bytes
+            if ws <= budget or bm <= 16:
+                return bm
+            self._plans.pop((T, bm), None)
+            nb = max(16, int(bm * budget / ws * 0.98) // 16 * 16)
+            bm = nb if nb < bm else max(16, bm - 16)
+
+    def _activate(self, T, B):
+        plan = self._make_plan(T, B)
+        if self._active is plan:
+            return plan
+        need = plan.workspace_bytes
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+        plan.bind(self._workspace, self._flat, self._gflat)
+        self._active = plan
+        return plan
+
+    # ------------------------------------------------------------------ noise
+    def set_noise(self, u, eps):
+        """Noise for the NEXT step: u[T,B,K] in [0,1) (Gumbel), eps[T,B,Z] ~ N(0,1)."""
+        self._pending_noise = (u, eps)
+
+    def _draw_noise(self, T, B):
+        dev = self._flat.device
+        if self._pending_noise is not None:
+            u, eps = self._pending_noise
+            self._pending_noise = None
+            u = torch.as_tensor(u, dtype=torch.float32, device=dev).contiguous()
+            eps = torch.as_tensor(eps, dtype=torch.float32, device=dev).contiguous()
+            assert tuple(u.shape) == (T, B, self.s_dim) and tuple(eps.shape) == (T, B, self.z_dim)
+            return u, eps
+        if self.noise_mode == 'reference':
+            u = torch.empty(T, B, self.s_dim)
+            eps = torch.empty(T, B, self.z_dim)
+            for t in range(T):  # samplers.py:25 then :60, per timestep, CPU generator
+                u[t] = torch.rand(B, self.s_dim)
+                eps[t] = torch.FloatTensor(B, self.z_dim).normal_()
+            return u.to(dev), eps.to(dev)
+        return (torch.rand(T, B, self.s_dim, device=dev), torch.randn(T, B, self.z_dim, device=dev))
+
+    # ------------------------------------------------------------------ the step
+    def _step(self, x, mask, beta, temp, grad, keep_params=False, inv_batch=None, collect=None):
+        """Run the fused step over micro-batches.  collect: list of output ids to gather ([T,B,w])."""
+        self._require_gpu()
+        dev = self._flat.device
+        x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+        mask = torch.as_tensor(mask, device=dev)
+        if mask.dtype != torch.bool:
+            mask = mask != 0
+        T, B, X = x.shape
+        assert X == self.x_dim, "x has %d columns, types_list implies %d" % (X, self.x_dim)
+        u, eps = self._draw_noise(T, B)
+        inv_batch = 1.0 / B if inv_batch is None else float(inv_batch)
+        losses = torch.zeros(16, dtype=torch.float32, device=dev)
+        flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
+        bm = self.micro_batch(T, B)
+        outs = {w: [] for w in (collect or [])}
+        persum = []
+        L = N.lib()
+        for b0 in range(0, B, bm):
+            b1 = min(B, b0 + bm)
+            plan = self._activate(T, b1 - b0)
+            if b0 == 0 and b1 == B:
+                xs, ms, us, es = x.contiguous(), mask.contiguous(), u, eps
+            else:
+                xs, ms = x[:, b0:b1].contiguous(), mask[:, b0:b1].contiguous()
+                us, es = u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous()
+            N.check(L.shivae_elbo_step(plan.h, N.ptr(xs), N.ptr(ms.view(torch.uint8)), N.ptr(us), N.ptr(es),
+                                       float(beta), float(temp), inv_batch, flags, N.ptr(losses), N.stream()))
+            for w in outs:
+                o = torch.empty(T, b1 - b0, plan.output_width(w), dtype=torch.float32, device=dev)
+                N.check(L.shivae_get_output(plan.h, w, N.ptr(o), N.stream()))
+                outs[w].append(o)
+            if collect is not None:
+                ps = torch.empty(b1 - b0, 6, dtype=torch.float32, device=dev)
+                N.check(L.shivae_get_persum(plan.h, N.ptr(ps), N.stream()))
+                persum.append(ps)
+        outs = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
+        self._last = dict(u=u, eps=eps, persum=torch.cat(persum) if persum else None)
+        return losses, outs
+
+    def forward(self, x, mask, beta=1., temp=3, inv_batch=None):
+        """base_missvae.py:144-164: dict of the 9 loss scalars (K*M == 1, so the ``repeat`` is a no-op).
+
+        In training mode with grad enabled the gradients of n_elbo are computed in the same pass;
+        ``loss['n_elbo'].backward()`` makes them visible as ``p.grad``."""
+        grad = torch.is_grad_enabled() and self.training
+        fresh = self._slices[0][0].grad is None
+        if grad and fresh:
+            self._gflat.zero_()
+        losses, _ = self._step(x, mask, beta, temp, grad, inv_batch=inv_batch)
+        vals = losses[:9]
+        if self.check_nan or self.print_losses:
+            host = vals.cpu()
+            if self.check_nan and bool(torch.isnan(host).any()):
+                bad = [k for k, v in zip(LOSS_KEYS, host.tolist()) if v != v]
+                print("%s Loss NAN" % ", ".join(bad))  # base_missvae.py:223-228, utils.py:171-175
+                raise SystemExit(1)
+            if self.print_losses:
+                print(print_shivae.format(**dict(zip(LOSS_KEYS, host.tolist()))))
+        loss_dict = {k: vals[i] for i, k in enumerate(LOSS_KEYS)}
+        if grad:
+            loss_dict['n_elbo'] = _AttachGrads.apply(self._hook, vals[0], self)
+        return loss_dict
+
+    # ------------------------------------------------------------------ reference API around the step
+    def _likes_from_params(self, dp):
+        """base_missvae.py:111-142 decparams2likes on the raw head outputs [T,B,P]."""
+        likes, off = {}, 0
+        for t in self.types_list:
+            ty, var = t['type'], t['name']
+            if ty in ('real', 'pos'):
+                mu = dp[..., off:off + 1]
+                if self.learn_std:
+                    std = torch.nn.functional.softplus(dp[..., off + 1:off + 2])
+                    off += 2
+                else:
+                    std = torch.full_like(mu, FIXED_STD)
+                    off += 1
+                likes[var] = torch.distributions.Normal(mu, std, validate_args=False)
+            elif ty == 'bin':
+                likes[var] = torch.distributions.Bernoulli(logits=dp[..., off:off + 1], validate_args=False)
+                off += 1
+            else:
+                C = int(t['dim'])
+                th = torch.cat([torch.zeros_like(dp[..., :1]), dp[..., off:off + C - 1]], dim=-1)  # decoders.py:169-170
+                likes[var] = torch.distributions.OneHotCategorical(logits=th, validate_args=False)
+                off += C - 1
+        return likes
+
+    def _params_from_likes(self, likes):
+        cols = []
+        for t in self.types_list:
+            lk, ty = likes[t['name']], t['type']
+            if ty in ('real', 'pos'):
+                cols.append(lk.loc)
+                if self.learn_std:
+                    s = lk.scale
+                    cols.append(torch.where(s > 20, s, torch.log(torch.expm1(s.clamp(max=20)))))  # inverse softplus
+            elif ty == 'bin':
+                cols.append(lk.logits)
+            else:
+                lg = lk.logits
+                cols.append((lg - lg[..., :1])[..., 1:])
+        return torch.cat(cols, dim=-1).contiguous().float()
+
+    @torch.no_grad()
+    def feed2model(self, x, temp=3):
+        """shivae.py:72-154: (z_tup, z_prior_tup, s_tup, likes)."""
+        O = N.O
+        want = [O["Z"], O["Z_MEAN"], O["Z_STD"], O["ZP_MEAN"], O["ZP_STD"], O["S"], O["S_PROBS"], O["DEC_PARAMS"]]
+        x = torch.as_tensor(x, dtype=torch.float32, device=self._flat.device)
+        _, o = self._step(x, torch.zeros_like(x, dtype=torch.bool), 1.0, temp, grad=False, keep_params=True, collect=want)
+        z_tup = [o[O["Z"]], o[O["Z_MEAN"]], o[O["Z_STD"]]]
+        z_prior_tup = [o[O["ZP_MEAN"]], o[O["ZP_STD"]]]
+        s_tup = [o[O["S"]], o[O["S_PROBS"]]]
+        self._last["dec_params"] = o[O["DEC_PARAMS"]]
+        return z_tup, z_prior_tup, s_tup, self._likes_from_params(o[O["DEC_PARAMS"]])
+
+    @torch.no_grad()
+    def heter_nll(self, x, mask, likes, types_list=None, eval_obs=False):
+        """base_missvae.py:233-285 via the HIP likelihood kernel: dict nll_<type> -> [B]."""
+        if types_list is not None and [t['name'] for t in types_list] != [t['name'] for t in self.types_list]:
+            raise NotImplementedError("heter_nll on a subset of the attributes")
+        self._require_gpu()
+        dev = self._flat.device
+        x = torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+        mask = torch.as_tensor(mask, device=dev)
+        mask = (mask != 0) if mask.dtype != torch.bool else mask
+        if eval_obs:
+            mask = ~mask  # :278-279 evaluate on the missing entries instead
+        T, B, _ = x.shape
+        P = self._params_from_likes(likes)
+        rowloss = torch.zeros(T * B, 6, device=dev)
+        N.check(N.lib().shivae_heter_nll(self._layout.h, N.ptr(x), N.ptr(mask.contiguous().view(torch.uint8)), N.ptr(P),
+                                         self.p_dim, None, T * B, 1.0, N.ptr(rowloss), N.stream()))
+        s = rowloss.view(T, B, 6).sum(dim=0)
+        return {"nll_" + k: s[:, i] for i, k in enumerate(LOSSES)}
+
+    @torch.no_grad()
+    def _kl_rows(self, z_tup, z_prior_tup, s_tup):
+        self._require_gpu()
+        dev = self._flat.device
+        _, mu, sd = [torch.as_tensor(a, dtype=torch.float32, device=dev).contiguous() for a in z_tup]
+        mup, sdp = [torch.as_tensor(a, dtype=torch.float32, device=dev).contiguous() for a in z_prior_tup]
+        probs = torch.as_tensor(s_tup[1], dtype=torch.float32, device=dev).contiguous()
+        T, B, Z = mu.shape
+        K = probs.shape[-1]
+        rowloss = torch.zeros(T * B, 6, device=dev)
+        N.check(N.lib().shivae_kl_terms(N.ptr(mu), N.ptr(sd), N.ptr(mup), N.ptr(sdp), Z, N.ptr(probs), K, T * B, Z, K,
+                                        1.0, None, None, None, None, None, N.ptr(rowloss), N.stream()))
+        return rowloss.view(T, B, 6)
+
+    def kl_q_z(self, z_tup, z_prior_tup):
+        """base_missvae.py:287-318 -> [B]."""
+        K = self.s_dim
+        dummy = torch.full(tuple(z_tup[1].shape[:2]) + (K,), 1.0 / K, device=self._flat.device)
+        return self._kl_rows(z_tup, z_prior_tup, (None, dummy))[..., 4].sum(dim=0)
+
+    def kl_q_s(self, s_tup):
+        """base_missvae.py:320-343 -> [B]."""
+        T, B, _ = s_tup[1].shape
+        one = torch.ones(T, B, 1, device=self._flat.device)
+        return self._kl_rows((None, one, one), (one, one), s_tup)[..., 5].sum(dim=0)
+
+    @torch.no_grad()
+    def compute_loss(self, x, mask, z_tup, z_prior_tup, likes, beta=1., s_tup=None):
+        """base_missvae.py:166-231 (Monte-Carlo branch, K == 1) from already computed tuples."""
+        nll = self.heter_nll(x, mask, likes)
+        nll_loss = sum(nll.values())
+        kl = self._kl_rows(z_tup, z_prior_tup, s_tup).sum(dim=0)
+        klz, kls = kl[:, 4], kl[:, 5]
+        out = {'n_elbo': (nll_loss + beta * klz + beta * kls).mean(), 'nll_loss': nll_loss.mean(),
+               'kld': klz.mean() + kls.mean(), 'kld_q_z': klz.mean(), 'kld_q_s': kls.mean()}
+        nll_mean = {k: v.mean() for k, v in nll.items()}
+        if torch.isnan(klz.sum()):
+            print("KL Loss NAN")
+            raise SystemExit(1)
+        utils.check_nan_losses(nll_mean)
+        return {**out, **nll_mean}
+
+    @torch.no_grad()
+    def reconstruction(self, x, temp=0.01):
+        """base_missvae.py:345-359: ((likes, x_hat), (z_tup, s_tup))."""
+        z_tup, z_prior_tup, s_tup, likes = self.feed2model(x, temp)
+        return (likes, self.generate_heter_samples(likes)), (z_tup, s_tup)
+
+    @torch.no_grad()
+    def generate_heter_samples(self, likes, n_samples=100):
+        """base_missvae.py:378-404: Monte-Carlo means (round for bin/cat), concatenated on the last dim."""
+        cols = []
+        for t in self.types_list:
+            lik = likes[t['name']]
+            m = torch.mean(lik.sample((n_samples,)), dim=0)
+            cols.append(torch.round(m) if t['type'] in ('bin', 'cat') else m)
+        return torch.cat(cols, dim=-1)
+
+    @torch.no_grad()
+    def impute_mean(self, x, temp=0.01):
+        """Monte-Carlo-free imputation: real/pos -> mean, bin -> [logit>0], cat -> one-hot argmax."""
+        _, _, _, likes = self.feed2model(x, temp)
+        cols = []
+        for t in self.types_list:
+            lik, ty = likes[t['name']], t['type']
+            if ty in ('real', 'pos'):
+                cols.append(lik.loc)
+            elif ty == 'bin':
+                cols.append((lik.logits > 0).float())
+            else:
+                cols.append(torch.nn.functional.one_hot(lik.logits.argmax(-1), int(t['dim'])).float())
+        return torch.cat(cols, dim=-1)
+
+    def sample_from_prior(self, batch_size, ts, temp=0.02):
+        raise NotImplementedError("generation from the prior (shivae.py:156-214) is outside the accelerated train/"
+                                  "imputation path (SURVEY.md 8f, row f4)")
+
+    def sample(self, batch_size, ts, temp=0.01):
+        return self.sample_from_prior(batch_size, ts, temp)
+
+    # ------------------------------------------------------------------ data parallel
+    def allreduce_grads(self):
+        """Sum the flat gradient buffer over the ranks (RCCL all-reduce over xGMI).  Each rank ran its
+        batch shard with inv_batch = 1/B_global, so the sum IS the global-batch gradient."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)

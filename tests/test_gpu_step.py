@@ -1,0 +1,190 @@
+"""GPU parity of the full fused step (ShiVAE host API -> C ABI -> HIP kernels) against the golden
+vectors of the reference and against the oracle on larger seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import _golden
+import shivae_amd
+from oracle import shivae_oracle as so
+from shivae_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+# stated fp32 tolerances (north_star "within a stated fp32 tolerance")
+FWD_RTOL, FWD_ATOL = 1e-4, 2e-5
+LOSS_RTOL = 2e-5
+GRAD_RTOL = 5e-4  # relative to the largest |grad| entry of each tensor
+
+
+def _model(cfg, sd):
+    m = shivae_amd.ShiVAE(cfg["H"], cfg["Z"], cfg["K"], 1, types_list=cfg["types_list"], learn_std=cfg["learn_std"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_forward_outputs_match_reference(name):
+    g, cfg, sd = _golden.load(name)
+    m = _model(cfg, sd)
+    m.set_noise(g["u"], g["eps"])
+    z_tup, zp_tup, s_tup, likes = m.feed2model(torch.from_numpy(g["x"]), cfg["temp"])
+    for t, k in zip(z_tup + zp_tup + s_tup, ("z", "z_mean", "z_std", "zp_mean", "zp_std", "s", "s_probs")):
+        np.testing.assert_allclose(t.cpu().numpy(), g[k], rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=k)
+    gp = _golden.golden_dec_params(g, cfg["types_list"])
+    for i, t in enumerate(cfg["types_list"]):
+        lk = likes[t["name"]]
+        if t["type"] in ("real", "pos"):
+            np.testing.assert_allclose(lk.loc[..., 0].cpu().numpy(), gp[i][0], rtol=FWD_RTOL, atol=FWD_ATOL)
+            np.testing.assert_allclose(lk.scale[..., 0].cpu().numpy(), gp[i][1], rtol=FWD_RTOL, atol=FWD_ATOL)
+        elif t["type"] == "bin":
+            np.testing.assert_allclose(lk.logits[..., 0].cpu().numpy(), gp[i], rtol=FWD_RTOL, atol=FWD_ATOL)
+        else:
+            lg = lk.logits.cpu().numpy()
+            np.testing.assert_allclose(lg - lg[..., :1], gp[i], rtol=FWD_RTOL, atol=FWD_ATOL)
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_losses_and_gradients_match_reference(name):
+    g, cfg, sd = _golden.load(name)
+    m = _model(cfg, sd)
+    m.train()
+    m.set_noise(g["u"], g["eps"])
+    loss = m(torch.from_numpy(g["x"]), torch.from_numpy(g["mask"]), beta=cfg["beta"], temp=cfg["temp"])
+    for k in shivae_amd.LOSS_KEYS:
+        np.testing.assert_allclose(float(loss[k]), g["loss/" + k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
+    loss["n_elbo"].backward()
+    for k, p in m.named_parameters():
+        ref = g["grad/" + k]
+        assert p.grad is not None, k
+        err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
+        assert err < GRAD_RTOL, (k, err)
+    # per-sequence sums (base_missvae.py:284,318,343)
+    ps = m._last["persum"]
+    assert ps is None or True
+
+
+@pytest.mark.parametrize("name", ["cfg1_T100_B8", "tiny_all"])
+def test_per_sequence_terms_and_reconstruction(name):
+    g, cfg, sd = _golden.load(name)
+    m = _model(cfg, sd)
+    m.eval()
+    x, mask = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    m.set_noise(g["u"], g["eps"])
+    losses, outs = m._step(x, mask, cfg["beta"], cfg["temp"], grad=False, collect=[N.O["ROWLOSS"]])
+    ps = m._last["persum"].cpu().numpy()
+    for i, ty in enumerate(("real", "pos", "bin", "cat")):
+        np.testing.assert_allclose(ps[:, i], g["nll_b/nll_" + ty], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ps[:, 4], g["klz_b"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ps[:, 5], g["kls_b"], rtol=1e-4, atol=1e-4)
+    # imputation parameters at temp 0.01 (base_missvae.py:345-359)
+    m.set_noise(g["u"], g["eps"])
+    (likes, x_hat), _ = m.reconstruction(x, temp=0.01)
+    gp = _golden.golden_dec_params(g, cfg["types_list"], prefix="rec")
+    for i, t in enumerate(cfg["types_list"]):
+        lk = likes[t["name"]]
+        if t["type"] in ("real", "pos"):
+            np.testing.assert_allclose(lk.loc[..., 0].cpu().numpy(), gp[i][0], rtol=1e-3, atol=1e-4)
+        elif t["type"] == "bin":
+            np.testing.assert_allclose(lk.logits[..., 0].cpu().numpy(), gp[i], rtol=1e-3, atol=1e-4)
+        else:
+            lg = lk.logits.cpu().numpy()
+            np.testing.assert_allclose(lg - lg[..., :1], gp[i], rtol=1e-3, atol=1e-4)
+    assert tuple(x_hat.shape) == tuple(g["x"].shape)
+
+
+def _synth(rng, tl, T, B, miss):
+    cols, mcols = [], []
+    for t in tl:
+        dim = int(t["dim"])
+        mk = rng.random((T, B)) < miss
+        if t["type"] in ("real", "pos"):
+            v = rng.standard_normal((T, B, 1))
+        elif t["type"] == "bin":
+            v = (rng.random((T, B, 1)) < 0.5).astype(np.float64)
+        else:
+            v = np.eye(dim)[rng.integers(0, dim, size=(T, B))]
+        cols.append(v); mcols.append(np.repeat(mk[..., None], dim, -1))
+    mask = np.concatenate(mcols, -1)
+    return np.where(mask, 0, np.concatenate(cols, -1)).astype(np.float32), mask
+
+
+CASES = {
+    # (types, T, B, H, Z, K, learn_std, miss, chunk_rows): shapes the golden set does not cover
+    "aligned_h32": (shivae_amd.utils.make_types_list(3, 2, 2, [4, 6], interleave=True), 9, 37, 32, 16, 16, True, 0.3, 0),
+    "ragged_chunks": (shivae_amd.utils.make_types_list(2, 2, 1, [3]), 11, 21, 20, 5, 4, True, 0.5, 64),
+    "h80_multiwave": (shivae_amd.utils.make_types_list(1, 1, 1, [5]), 6, 18, 80, 24, 6, False, 0.3, 0),
+    "cat_heavy_miss90": (shivae_amd.utils.make_types_list(1, 1, 1, [8] * 7), 8, 19, 24, 8, 8, True, 0.9, 0),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_step_matches_oracle_on_seeded_inputs(name):
+    tl, T, B, H, Z, K, learn_std, miss, chunk = CASES[name]
+    rng = np.random.default_rng(abs(hash(name)) % 2**31)
+    P = so.init_params(tl, H, Z, K, learn_std, seed=1)
+    for k in P:
+        if "bias" in k:
+            P[k] = (rng.standard_normal(P[k].shape) * 0.1).astype(np.float32)
+    x, mask = _synth(rng, tl, T, B, miss)
+    u = rng.random((T, B, K)).astype(np.float32)
+    eps = rng.standard_normal((T, B, Z)).astype(np.float32)
+    beta, temp = 0.8, 1.5
+    om = so.OracleShiVAE(P, tl, H, Z, K, learn_std)
+    c = om.forward(x, mask, u, eps, beta, temp)
+    G = om.backward()
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=learn_std)
+    m.chunk_rows = chunk
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m.train()
+    m.set_noise(u, eps)
+    loss = m(torch.from_numpy(x), torch.from_numpy(mask), beta=beta, temp=temp)
+    for k in shivae_amd.LOSS_KEYS:
+        np.testing.assert_allclose(float(loss[k]), c["losses"][k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
+    loss["n_elbo"].backward()
+    for k, p in m.named_parameters():
+        err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
+        assert err < GRAD_RTOL, (k, err)
+
+
+def test_micro_batches_equal_one_batch():
+    """Splitting the batch (what data parallelism and large-B runs do) leaves loss and grads unchanged."""
+    tl, T, B, H, Z, K, learn_std, miss, _ = CASES["aligned_h32"]
+    rng = np.random.default_rng(7)
+    x, mask = _synth(rng, tl, T, B, miss)
+    u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+    torch.manual_seed(0)
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=learn_std)
+    m.train()
+    m.set_noise(u, eps)
+    l1 = m(torch.from_numpy(x), torch.from_numpy(mask))
+    l1["n_elbo"].backward()
+    g1 = m.flat_grads.clone()
+    m.zero_grad()
+    m.micro_batch = lambda T_, B_: 16
+    m.set_noise(u, eps)
+    l2 = m(torch.from_numpy(x), torch.from_numpy(mask))
+    l2["n_elbo"].backward()
+    np.testing.assert_allclose(float(l2["n_elbo"]), float(l1["n_elbo"]), rtol=1e-5)
+    scale = float(g1.abs().max())
+    assert float((m.flat_grads - g1).abs().max()) / scale < 1e-4
+
+
+def test_train_loop_reduces_loss():
+    """A few Adam steps through the reference-style loop (trainers.py:209-224) on the HIP path."""
+    tl = shivae_amd.utils.make_types_list(1, 1, 1, [3])
+    rng = np.random.default_rng(1)
+    x, mask = _synth(rng, tl, 20, 32, 0.3)
+    torch.manual_seed(0)
+    m = shivae_amd.ShiVAE(10, 2, 3, 1, types_list=tl, learn_std=True)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    xt, mt = torch.from_numpy(x).cuda(), torch.from_numpy(mask).cuda()
+    vals = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = m(xt, mt, beta=1.0, temp=3)
+        loss["n_elbo"].backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 0.5)
+        opt.step()
+        vals.append(float(loss["n_elbo"]))
+    assert vals[-1] < vals[0]
