@@ -3,5 +3,6 @@ reference's Python API (``ShiVAE``, ``Trainer``).  See DESIGN.md / INTEGRATION.m
 from . import _native  # noqa: F401
 from . import utils  # noqa: F401
 from .shivae import ShiVAE, LOSS_KEYS  # noqa: F401
+from .optim import FusedClipAdam  # noqa: F401
 
-__all__ = ["ShiVAE", "LOSS_KEYS", "utils"]
+__all__ = ["ShiVAE", "FusedClipAdam", "LOSS_KEYS", "utils"]

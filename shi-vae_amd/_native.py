@@ -29,7 +29,7 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_
            "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
-           "shivae_clip_adam"]
+           "shivae_clip_adam", "shivae_profile_start", "shivae_profile_stop"]
 
 
 class Config(C.Structure):
@@ -81,6 +81,8 @@ def lib():
     L.shivae_zero.argtypes = [vp, i64, vp]
     L.shivae_sqnorm.argtypes = [vp, i64, vp, vp, vp]
     L.shivae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, cf, cf, cf, cf, cf, ci, vp]
+    L.shivae_profile_start.argtypes = []
+    L.shivae_profile_stop.argtypes = [C.POINTER(C.c_double), ci]
     _lib = L
     return L
 
@@ -154,3 +156,28 @@ class Plan:
 
     def output_width(self, which):
         return int(lib().shivae_output_width(self.h, which))
+
+
+_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128"]
+_LAYOUTS = ["NT", "NN", "TN"]
+
+
+def profile_name(i):
+    i = int(i)
+    if i < 15:
+        return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 5], _TILES[i % 5])
+    return {15: "scan_fwd_kernel", 16: "scan_bwd_kernel", 17: "heter_nll_kernel", 18: "kl_kernel"}[i]
+
+
+def profile_start():
+    check(lib().shivae_profile_start())
+
+
+def profile_stop():
+    """-> list of dicts {id, name, launches, ms, work} (work: flops, or bytes for the loss kernels)."""
+    buf = (C.c_double * (4 * 32))()
+    n = lib().shivae_profile_stop(buf, 32)
+    if n < 0:
+        check(n)
+    return [dict(id=int(buf[4 * i]), name=profile_name(buf[4 * i]), launches=int(buf[4 * i + 1]), ms=buf[4 * i + 2],
+                 work=buf[4 * i + 3]) for i in range(n)]

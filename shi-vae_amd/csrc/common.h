@@ -33,6 +33,12 @@ void set_error(const char* fmt, ...);
         if (r__ != SHIVAE_OK) return r__;                                               \
     } while (0)
 
+// ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
+// ids 0..14: gemm_kernel variants = layout*5 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128)
+enum ProfId { PROF_SCAN_FWD = 15, PROF_SCAN_BWD = 16, PROF_NLL = 17, PROF_KL = 18, PROF_COUNT = 19 };
+void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
+void prof_end(hipStream_t s);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

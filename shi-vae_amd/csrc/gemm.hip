@@ -191,10 +191,15 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
 static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int layout = A_KC ? (B_KC ? GEMM_NT : GEMM_NN) : GEMM_TN;
+    constexpr int tile = (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
+                       : (BM == 64 && BN == 256) ? 3 : 4;
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
     SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
                ngroups, p.splitk);
+    prof_begin(layout * 5 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
+    prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
 }

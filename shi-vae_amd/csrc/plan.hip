@@ -26,6 +26,22 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- HIP-event profiler: one (start, stop) pair per launch, resolved when the caller collects
+struct ProfRec { int id; double work; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+void prof_begin(int id, double work, hipStream_t s) {
+    if (!g_prof_on) return;
+    ProfRec r{id, work, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t s) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().b, s);
+}
+
 struct Tensor {
     int64_t off = -1;
     int rows = 0, cols = 0;
@@ -424,7 +440,12 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
 
     // 2. the serial chain
     ScanArgs sa = scan_args(p, u, eps, temp);
+    // serial-chain flops per (t,b): SURVEY.md 8d (k2 h-part, k2 out, k4 s+h parts, enc.2, mean/std, phi_z, LSTM)
+    const double scan_flops = 2.0 * ((double)H * H + (double)H * K + (double)(H + K) * H + (double)H * H +
+                                     2.0 * H * Z + (double)Z * H + 8.0 * H * H) * (double)R;
+    prof_begin(PROF_SCAN_FWD, scan_flops, s);
     SV_TRY(launch_scan(sa, false, s));
+    prof_end(s);
 
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
     if (grad) SV_CHECK_HIP(hipMemsetAsync(d_emb, 0, (size_t)R * Ep * sizeof(float), s));
@@ -452,11 +473,13 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wpm, H, mupc, Zp, p->prm(g[SHIVAE_P_PRIORMEAN_B]), nullptr, 0, EPI_BIAS, s));
         SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wps, H, sdpc, Zp, p->prm(g[SHIVAE_P_PRIORSTD_B]), nullptr, 0,
                      EPI_BIAS | EPI_SOFTPLUS, s));
+        prof_begin(PROF_KL, (double)rc * (16.0 * Z + 4.0 * K) * (grad ? 2.0 : 1.0), s);
         SV_TRY(launch_kl(p->wsf("mu") + (size_t)r0 * Zp, p->wsf("sd") + (size_t)r0 * Zp, mupc, sdpc, Zp,
                          p->wsf("probs") + (size_t)r0 * Kp, Kp, grad ? p->wsf("dmu_ext") + (size_t)r0 * Zp : nullptr,
                          grad ? p->wsf("dsd_ext") + (size_t)r0 * Zp : nullptr, grad ? dmupc : nullptr,
                          grad ? dsdpc : nullptr, grad ? p->wsf("dlg_kl") + (size_t)r0 * Kp : nullptr, rc, Z, K, kz,
                          rowloss + (size_t)r0 * 6, s));
+        prof_end(s);
         // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
         SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
                      nullptr, 0, EPI_BIAS | EPI_RELU, s));
@@ -469,8 +492,11 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         }
         if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
                                               hipMemcpyDeviceToDevice, s));
+        // algorithmic bytes per row: x (4X) + mask (X) + parameters (4P), + the gradient write (4P) in training
+        prof_begin(PROF_NLL, (double)rc * (5.0 * X + 4.0 * P * (grad ? 2.0 : 1.0)), s);
         SV_TRY(launch_heter_nll(p->attrs_dev, D, p->learn_std, x + (size_t)r0 * X, X, mask + (size_t)r0 * X, X, pbuf, P,
                                 grad ? pbuf : nullptr, P, rc, inv_batch, rowloss + (size_t)r0 * 6, s));
+        prof_end(s);
         if (!grad) continue;
 
         // ---- decoder backward (pbuf now holds d nll / d head outputs) ----
@@ -514,7 +540,9 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
 
     if (grad) {
         // 4. reverse-time scan
+        prof_begin(PROF_SCAN_BWD, 2.0 * scan_flops, s);
         SV_TRY(launch_scan(sa, true, s));
+        prof_end(s);
         // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics)
         const float *phiz = emb, *s_t = emb + Hp, *hprev = emb + Hp + Kp;
         float *d_gates = p->wsf("d_gates"), *d_phz = p->wsf("d_phiz_pre"), *d_mu = p->wsf("d_mu"),
@@ -790,6 +818,31 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0};
     GemmGroup g{A, B, C, bias, aux};
     return launch_gemm(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
+}
+
+int shivae_profile_start(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return SHIVAE_OK;
+}
+
+int shivae_profile_stop(double* out, int max_entries) {
+    g_prof_on = false;
+    SV_CHECK_HIP(hipDeviceSynchronize());
+    double calls[PROF_COUNT] = {0}, ms[PROF_COUNT] = {0}, work[PROF_COUNT] = {0};
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.id >= 0 && r.id < PROF_COUNT) {
+            calls[r.id] += 1; ms[r.id] += t; work[r.id] += r.work;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    int n = 0;
+    for (int i = 0; i < PROF_COUNT && n < max_entries; ++i)
+        if (calls[i] > 0) { out[4 * n] = i; out[4 * n + 1] = calls[i]; out[4 * n + 2] = ms[i]; out[4 * n + 3] = work[i]; ++n; }
+    return n;
 }
 
 int shivae_zero(float* buf, int64_t n, shivae_stream stream) {

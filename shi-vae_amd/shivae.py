@@ -306,6 +306,9 @@ class ShiVAE(nn.Module):
         losses = torch.zeros(16, dtype=torch.float32, device=dev)
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
         bm = self.micro_batch(T, B)
+        if bm < B:  # equal-sized micro-batches (one plan, no re-binding), multiples of the 16-sequence scan tile
+            nmb = -(-B // bm)
+            bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
         outs = {w: [] for w in (collect or [])}
         persum = []
         L = N.lib()

@@ -1,0 +1,51 @@
+"""Device-side synthetic heterogeneous-HMM batches for benchmarks (shape + statistics of
+src/hmm_dataset/heterHMMdataset.py: K-state Markov chain :76-94, per-state Gaussian / softplus-Gaussian /
+Bernoulli / dominant-class categorical emissions :127-249, burst missing masks :292-363), already
+scaled (standardised real, log1p-standardised pos), one-hot expanded and zero-filled, time-major."""
+import torch
+
+
+def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda", chunk=1024):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    xs, ms = [], []
+    for b0 in range(0, B, chunk):
+        b = min(chunk, B - b0)
+        # hidden chain: stay with prob 0.9, else jump to a uniformly random state
+        st = torch.empty(T, b, dtype=torch.long, device=device)
+        cur = torch.randint(0, n_states, (b,), generator=g, device=device)
+        for t in range(T):
+            jump = torch.rand(b, generator=g, device=device) < 0.1
+            cur = torch.where(jump, torch.randint(0, n_states, (b,), generator=g, device=device), cur)
+            st[t] = cur
+        cols, mcols = [], []
+        for d, ty in enumerate(types_list):
+            kind, dim = ty["type"], int(ty["dim"])
+            if kind in ("real", "pos"):
+                means = torch.linspace(-20, 20, n_states, device=device).roll(d % n_states)
+                v = means[st] + 0.5 * torch.randn(T, b, generator=g, device=device)
+                if kind == "pos":
+                    v = torch.log1p(torch.nn.functional.softplus(v))
+                v = (v - v.mean()) / (v.std() + 1e-6)
+                cols.append(v.unsqueeze(-1))
+            elif kind == "bin":
+                cols.append((((st + d) % 2) == 0).float().unsqueeze(-1))
+            else:
+                dom = (st + d) % dim
+                other = torch.randint(0, dim, (T, b), generator=g, device=device)
+                keep = torch.rand(T, b, generator=g, device=device) < 0.9
+                cols.append(torch.nn.functional.one_hot(torch.where(keep, dom, other), dim).float())
+            # bursts of length U(3,10) until ~round(T*miss) steps are masked
+            nb = max(1, int(round(T * miss / 6.5)))
+            start = torch.randint(0, T, (nb, b), generator=g, device=device)
+            length = torch.randint(3, 11, (nb, b), generator=g, device=device)
+            diff = torch.zeros(T + 1, b, device=device)
+            diff.scatter_add_(0, start, torch.ones(nb, b, device=device))
+            diff.scatter_add_(0, torch.clamp(start + length, max=T), -torch.ones(nb, b, device=device))
+            m = diff.cumsum(0)[:T] > 0
+            mcols.append(m.unsqueeze(-1).expand(T, b, dim))
+        x = torch.cat(cols, -1)
+        m = torch.cat(mcols, -1)
+        xs.append(torch.where(m, torch.zeros_like(x), x))
+        ms.append(m)
+    return torch.cat(xs, 1).contiguous(), torch.cat(ms, 1).contiguous()
