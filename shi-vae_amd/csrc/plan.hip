@@ -63,6 +63,7 @@ using namespace shivae;
 
 struct shivae_plan {
     int T, B, H, Z, K, X, D, P, E, Hp, Zp, Kp, Ep, E4, Z4, learn_std;
+    int ldA0, ldA1, ldHH;  // leading dims of the decoder activations (+64 floats: no power-of-two row strides)
     int64_t R;
     int Rc;
     int nbc;  // attributes with a hidden head layer (bin/cat)
@@ -208,11 +209,11 @@ static void build_workspace(shivae_plan* p) {
     carve(p, "dprc", Rc * Hp, cur);
     carve(p, "dmupc", Rc * Zp, cur);
     carve(p, "dsdp_prec", Rc * Zp, cur);
-    carve(p, "a0", Rc * D * 2 * H, cur);
-    carve(p, "da0", Rc * D * 2 * H, cur);
-    for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Rc * D * H, cur);
-    carve(p, "hh", Rc * std::max(p->nbc, 1) * H, cur);
-    carve(p, "dhh", Rc * std::max(p->nbc, 1) * H, cur);
+    carve(p, "a0", Rc * p->ldA0, cur);
+    carve(p, "da0", Rc * p->ldA0, cur);
+    for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Rc * p->ldA1, cur);
+    carve(p, "hh", Rc * p->ldHH, cur);
+    carve(p, "dhh", Rc * p->ldHH, cur);
     carve(p, "pbuf", Rc * p->P, cur);
     carve(p, "wpack", p->wpack_floats, cur);
     p->ws_bytes = cur;
@@ -459,7 +460,7 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
                 *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
     const float kz = beta * inv_batch;
-    const int ldA0 = D * 2 * H, ldA1 = D * H, ldHH = std::max(p->nbc, 1) * H;
+    const int ldA0 = p->ldA0, ldA1 = p->ldA1, ldHH = p->ldHH;
     for (int r0 = 0; r0 < R; r0 += p->Rc) {
         const int rc = std::min(p->Rc, R - r0);
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
@@ -642,6 +643,7 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         delete p;
         return SHIVAE_ERR_INVALID;
     }
+    p->ldA0 = p->D * 2 * p->H + 64; p->ldA1 = p->D * p->H + 64; p->ldHH = std::max(p->nbc, 1) * p->H + 64;
     build_layout(p);
     {
         std::vector<PackJob> wj, bj;

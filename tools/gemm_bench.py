@@ -1,0 +1,40 @@
+"""Isolated timing of the fp32 MFMA GEMM through the C ABI (shivae_gemm): python tools/gemm_bench.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shivae_amd import _native as N
+
+L = N.lib()
+
+def run(layout, M, Nn, K, lda, ldb, ldc, epi=0, splitk=1, iters=5, tag=""):
+    rowsA = M if layout != 2 else K
+    rowsB = Nn if layout == 0 else K
+    A = torch.randn(rowsA, lda, device="cuda")
+    B = torch.randn(rowsB, ldb, device="cuda")
+    C = torch.zeros(M, ldc, device="cuda")
+    def go():
+        N.check(L.shivae_gemm(layout, M, Nn, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C), ldc, None, None, 0, epi, splitk, N.stream()))
+    go(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): go()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print("%-34s layout=%d M=%6d N=%6d K=%6d lda=%7d ldb=%7d  %8.3f ms  %6.1f TF" % (tag, layout, M, Nn, K, lda, ldb, ms, 2.0*M*Nn*K/ms/1e9), flush=True)
+
+R = 16384
+run(0, R, 512, 528, 528, 528, 512, tag="NT contiguous")
+run(0, R, 4096, 528, 528, 528, 4096, tag="NT wide N")
+run(0, R, 256, 512, 512, 512, 256, tag="NT L1 contiguous")
+run(0, R, 256, 512, 131072, 512, 65536, tag="NT L1 lda=131072 (pow2)")
+run(0, R, 256, 512, 131072 + 64, 512, 65536 + 64, tag="NT L1 lda padded")
+run(0, 4096, 4096, 4096, 4096, 4096, 4096, tag="NT 4096^3")
+run(1, R, 512, 256, 256, 512, 512, tag="NN dL1 contiguous")
+run(1, R, 512, 256, 65536, 512, 131072, tag="NN dL1 pow2 ld")
+run(1, R, 512, 256, 65536 + 64, 512, 131072 + 64, tag="NN dL1 padded ld")
+run(1, R, 528, 8192, 8192, 528, 528, tag="NN dL0 K=8192")
+run(1, 4096, 4096, 4096, 4096, 4096, 4096, tag="NN 4096^3")
+run(2, 512, 528, R, 512, 528, 528, epi=32, splitk=8, tag="TN wgrad splitk8")
+run(2, 256, 512, R, 65536, 131072, 512, epi=32, splitk=8, tag="TN wL1 pow2 ld")
+run(2, 256, 512, R, 65536 + 64, 131072 + 64, 512, epi=32, splitk=8, tag="TN wL1 padded ld")
+run(2, 4096, 4096, 4096, 4096, 4096, 4096, tag="TN 4096^3")
