@@ -143,7 +143,7 @@ def main():
     ms_step = dt / a.steps * 1e3
     value = B * T * a.steps / dt
 
-    gemms = [p for p in prof if p["id"] < 15]
+    gemms = [p for p in prof if p["id"] < 18]
     dom = max(gemms, key=lambda p: p["ms"]) if gemms else None
     roof = None
     if dom:
@@ -159,7 +159,7 @@ def main():
         e = {"kernel": p["name"], "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
              "share_of_step": p["ms"] / (dt * 1e3)}
         rate = p["work"] / (p["ms"] * 1e-3)
-        if p["id"] >= 17:
+        if p["id"] >= 20:
             e.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
         else:
             e.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",

@@ -183,9 +183,9 @@ int shivae_clip_adam(float* params_dev, const float* grads_dev, float* exp_avg_d
 /* ---- measurement support (no counterpart in the reference) ---------------------------------- */
 /* Bracket every kernel launch of the following calls with HIP events on the launch stream.
  * shivae_profile_stop synchronises the device and writes up to max_entries records of 4 doubles
- * {kernel id, launches, total ms, total work} and returns the record count.  ids 0..14 are the
- * GEMM kernel variants (layout*5 + tile; work = flops), 15/16 the recurrent scan fwd/bwd (flops),
- * 17 the likelihood kernel, 18 the KL kernel (work = algorithmic bytes).  Not thread-safe. */
+ * {kernel id, launches, total ms, total work} and returns the record count.  ids 0..17 are the
+ * GEMM kernel variants (layout*6 + tile; work = flops), 18/19 the recurrent scan fwd/bwd (flops),
+ * 20 the likelihood kernel, 21 the KL kernel (work = algorithmic bytes).  Not thread-safe. */
 int shivae_profile_start(void);
 int shivae_profile_stop(double* out, int max_entries);
 

@@ -158,15 +158,15 @@ class Plan:
         return int(lib().shivae_output_width(self.h, which))
 
 
-_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128"]
+_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128", "128x256"]
 _LAYOUTS = ["NT", "NN", "TN"]
 
 
 def profile_name(i):
     i = int(i)
-    if i < 15:
-        return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 5], _TILES[i % 5])
-    return {15: "scan_fwd_kernel", 16: "scan_bwd_kernel", 17: "heter_nll_kernel", 18: "kl_kernel"}[i]
+    if i < 18:
+        return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 6], _TILES[i % 6])
+    return {18: "scan_fwd_kernel", 19: "scan_bwd_kernel", 20: "heter_nll_kernel", 21: "kl_kernel"}[i]
 
 
 def profile_start():

@@ -19,6 +19,7 @@
 // B[k=l>>5][j=l&31]; with per-lane float4 v = X[.][8s+4h .. 8s+4h+3] (h = l>>5), MFMA number c uses
 // v[c] on both sides, i.e. the k pair {8s+c, 8s+4+c}.  D: col = l&31, row = (r&3)+8*(r>>2)+4*h.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -28,15 +29,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
-template <bool KC, int ROWS, int NT>
+template <bool KC, int ROWS, int NT, bool VEC>
 struct TileLoader {
     // KC : global X[row*ld + k], tile rows = ROWS along the M/N extent, 32 along K
     // !KC: global X[k*ld + row]
+    // Loads are UNCONDITIONAL (out-of-range lanes read X[0] and are zeroed by a select): a branch
+    // around a load makes hipcc wait vmcnt(0) per element and serialises the whole tile fetch.
     static constexpr int NV = ROWS * 8 / NT;  // float4 per thread
     float4 v[NV > 0 ? NV : 1];
 
     __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int row0, int nrows, int k0,
-                                         int kend, bool vec, int tid) {
+                                         int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = tid + i * NT;
@@ -44,31 +47,21 @@ struct TileLoader {
             if (KC) { r = f >> 3; k = (f & 7) * 4; }
             else    { k = f / (ROWS / 4); r = (f % (ROWS / 4)) * 4; }
             const int gr = row0 + r, gk = k0 + k;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KC) {
-                if (gr < nrows) {
-                    const float* p = X + (size_t)gr * ld + gk;
-                    if (vec && gk + 3 < kend) x = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (gk + 0 < kend) x.x = p[0];
-                        if (gk + 1 < kend) x.y = p[1];
-                        if (gk + 2 < kend) x.z = p[2];
-                        if (gk + 3 < kend) x.w = p[3];
-                    }
-                }
+            const size_t off = KC ? (size_t)gr * ld + gk : (size_t)gk * ld + gr;
+            if (VEC) {  // contiguous extent is a multiple of 4: a float4 is all-valid or all-invalid
+                const bool ok = gr < nrows && gk < kend;
+                const float4 x = *reinterpret_cast<const float4*>(X + (ok ? off : 0));
+                v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                if (gk < kend) {
-                    const float* p = X + (size_t)gk * ld + gr;
-                    if (vec && gr + 3 < nrows) x = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (gr + 0 < nrows) x.x = p[0];
-                        if (gr + 1 < nrows) x.y = p[1];
-                        if (gr + 2 < nrows) x.z = p[2];
-                        if (gr + 3 < nrows) x.w = p[3];
-                    }
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool ok = KC ? (gr < nrows && gk + c < kend) : (gk < kend && gr + c < nrows);
+                    const float t = X[ok ? off + c : 0];
+                    e[c] = ok ? t : 0.f;
                 }
+                v[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
-            v[i] = x;
         }
     }
 
@@ -97,7 +90,7 @@ struct GemmParams {
     GemmGroup g0;
 };
 
-template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int LDS_A = A_KC ? BM * 36 : 32 * BM;
@@ -123,19 +116,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    TileLoader<A_KC, BM, NT> la;
-    TileLoader<B_KC, BN, NT> lb;
+    TileLoader<A_KC, BM, NT, VEC> la;
+    TileLoader<B_KC, BN, NT, VEC> lb;
     if (kbeg < kend) {
-        la.load(g.A, p.lda, m0, p.M, kbeg, kend, p.vecA, tid);
-        lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, p.vecB, tid);
+        la.load(g.A, p.lda, m0, p.M, kbeg, kend, tid);
+        lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid);
     }
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         la.store(ldsA, tid);
         lb.store(ldsB, tid);
         __syncthreads();
         if (k0 + 32 < kend) {
-            la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, p.vecA, tid);
-            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, p.vecB, tid);
+            la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
+            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -188,30 +181,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int TM, int TN>
+template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
 static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int layout = A_KC ? (B_KC ? GEMM_NT : GEMM_NN) : GEMM_TN;
     constexpr int tile = (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
-                       : (BM == 64 && BN == 256) ? 3 : 4;
+                       : (BM == 64 && BN == 256) ? 3 : (BM == 128 && BN == 128) ? 4 : 5;
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
     SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
                ngroups, p.splitk);
-    prof_begin(layout * 5 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
-    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
+    prof_begin(layout * 6 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
 }
 
+template <bool A_KC, bool B_KC, bool VEC>
+static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
+    // tile choice: 128x128 by default; skinny shapes get a 32-wide tile on the skinny side
+    if (p.N <= 32) return launch_cfg<A_KC, B_KC, VEC, 4, 1, 2, 1>(p, ngroups, stream);   // 256 x 32
+    if (p.M <= 32) return launch_cfg<A_KC, B_KC, VEC, 1, 4, 1, 2>(p, ngroups, stream);   // 32 x 256
+    if (p.N <= 64) return launch_cfg<A_KC, B_KC, VEC, 4, 1, 2, 2>(p, ngroups, stream);   // 256 x 64
+    if (p.M <= 64) return launch_cfg<A_KC, B_KC, VEC, 1, 4, 2, 2>(p, ngroups, stream);   // 64 x 256
+    const char* force = getenv("SHIVAE_GEMM_TILE");
+    const int mode = force ? atoi(force) : 0;
+    if (mode == 1 || (mode == 0 && p.N >= 256 && (p.N % 256 == 0 || p.N % 256 > 128)))
+        return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 4>(p, ngroups, stream);               // 128 x 256
+    return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2>(p, ngroups, stream);                  // 128 x 128
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_layout(const GemmParams& p, int ngroups, hipStream_t stream) {
-    // tile choice: 128x128 by default; skinny shapes get a 32-wide tile on the skinny side
-    if (p.N <= 32) return launch_cfg<A_KC, B_KC, 4, 1, 2, 1>(p, ngroups, stream);   // 256 x 32
-    if (p.M <= 32) return launch_cfg<A_KC, B_KC, 1, 4, 1, 2>(p, ngroups, stream);   // 32 x 256
-    if (p.N <= 64) return launch_cfg<A_KC, B_KC, 4, 1, 2, 2>(p, ngroups, stream);   // 256 x 64
-    if (p.M <= 64) return launch_cfg<A_KC, B_KC, 1, 4, 2, 2>(p, ngroups, stream);   // 64 x 256
-    return launch_cfg<A_KC, B_KC, 2, 2, 2, 2>(p, ngroups, stream);                  // 128 x 128
+    if (p.vecA && p.vecB) return launch_tiles<A_KC, B_KC, true>(p, ngroups, stream);
+    return launch_tiles<A_KC, B_KC, false>(p, ngroups, stream);
 }
 
 int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,

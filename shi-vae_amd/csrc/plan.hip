@@ -377,6 +377,16 @@ static int splitk_for(int M, int N, int K, int groups) {
 
 static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                  const float* bias, const float* aux, int ldaux, int epi, hipStream_t s) {
+    // A few columns past a multiple of 128 (E = 2H+K = 528 at H=256, K=16) would cost a whole extra
+    // 128-wide tile column: run them as a separate skinny launch instead.
+    const int rem = N % 128;
+    if (N > 128 && rem > 0 && rem <= 32 && M > 64) {
+        const int Nm = N - rem;
+        SV_TRY(gemm1(layout, M, Nm, K, A, lda, B, ldb, C, ldc, bias, aux, ldaux, epi, s));
+        const float* B2 = layout == GEMM_NT ? B + (size_t)Nm * ldb : B + Nm;
+        return gemm1(layout, M, rem, K, A, lda, B2, ldb, C + Nm, ldc, bias ? bias + Nm : nullptr,
+                     aux ? aux + Nm : nullptr, ldaux, epi, s);
+    }
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, 0};
     if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, 1);
     GemmGroup g{A, B, C, bias, aux};
