@@ -38,6 +38,7 @@ void set_error(const char* fmt, ...);
 enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_COUNT = 22 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);
+void prof_shape(int M, int N, int K, int G);  // optional detail for the next prof_begin
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -91,7 +91,7 @@ struct GemmParams {
 };
 
 template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_kernel(GemmParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int LDS_A = A_KC ? BM * 36 : 32 * BM;
     constexpr int LDS_B = B_KC ? BN * 36 : 32 * BN;
@@ -190,6 +190,7 @@ static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
     SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
                ngroups, p.splitk);
+    prof_shape(p.M, p.N, p.K, ngroups);
     prof_begin(layout * 6 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
     prof_end(stream);
@@ -206,7 +207,7 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     if (p.M <= 64) return launch_cfg<A_KC, B_KC, VEC, 1, 4, 2, 2>(p, ngroups, stream);   // 64 x 256
     const char* force = getenv("SHIVAE_GEMM_TILE");
     const int mode = force ? atoi(force) : 0;
-    if (mode == 1 || (mode == 0 && p.N >= 256 && (p.N % 256 == 0 || p.N % 256 > 128)))
+    if (mode == 1)
         return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 4>(p, ngroups, stream);               // 128 x 256
     return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2>(p, ngroups, stream);                  // 128 x 128
 }

@@ -27,12 +27,15 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- HIP-event profiler: one (start, stop) pair per launch, resolved when the caller collects
-struct ProfRec { int id; double work; hipEvent_t a, b; };
+struct ProfRec { int id; double work; hipEvent_t a, b; int M, N, K, G; };
+static int g_pm = 0, g_pn = 0, g_pk = 0, g_pg = 0;
+void prof_shape(int M, int N, int K, int G) { g_pm = M; g_pn = N; g_pk = K; g_pg = G; }
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 void prof_begin(int id, double work, hipStream_t s) {
     if (!g_prof_on) return;
-    ProfRec r{id, work, nullptr, nullptr};
+    ProfRec r{id, work, nullptr, nullptr, g_pm, g_pn, g_pk, g_pg};
+    g_pm = g_pn = g_pk = g_pg = 0;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
@@ -384,6 +387,12 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
         const int Nm = N - rem;
         SV_TRY(gemm1(layout, M, Nm, K, A, lda, B, ldb, C, ldc, bias, aux, ldaux, epi, s));
         const float* B2 = layout == GEMM_NT ? B + (size_t)Nm * ldb : B + Nm;
+        if (epi == 0 && K >= 4096) {
+            // long-K skinny remainder: too few tiles to fill the chip -> zero the columns, split K, add atomically
+            SV_CHECK_HIP(hipMemset2DAsync(C + Nm, (size_t)ldc * sizeof(float), 0, (size_t)rem * sizeof(float), M, s));
+            GemmDesc d{layout, M, rem, K, lda, ldb, ldc, 0, EPI_ATOMIC, std::min(32, ceil_div(K, 2048)), 0};
+            return launch_gemm(d, nullptr, 1, GemmGroup{A, B2, C + Nm, nullptr, nullptr}, s);
+        }
         return gemm1(layout, M, rem, K, A, lda, B2, ldb, C + Nm, ldc, bias ? bias + Nm : nullptr,
                      aux ? aux + Nm : nullptr, ldaux, epi, s);
     }
@@ -848,8 +857,22 @@ int shivae_profile_stop(double* out, int max_entries) {
         if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.id >= 0 && r.id < PROF_COUNT) {
             calls[r.id] += 1; ms[r.id] += t; work[r.id] += r.work;
         }
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
+    if (getenv("SHIVAE_PROF_DETAIL")) {  // per-shape table on stderr
+        std::map<std::vector<int>, std::pair<double, double>> tab;
+        std::map<std::vector<int>, int> cnt;
+        for (auto& r : g_prof) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+            std::vector<int> key{r.id, r.M, r.N, r.K, r.G};
+            tab[key].first += t; tab[key].second += r.work; cnt[key]++;
+        }
+        for (auto& kv : tab)
+            fprintf(stderr, "prof id=%2d M=%7d N=%7d K=%7d G=%4d launches=%4d ms=%9.3f rate=%8.2f T/s\n", kv.first[0],
+                    kv.first[1], kv.first[2], kv.first[3], kv.first[4], cnt[kv.first], kv.second.first,
+                    kv.second.second / (kv.second.first * 1e-3) / 1e12);
+    }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     int n = 0;
     for (int i = 0; i < PROF_COUNT && n < max_entries; ++i)
