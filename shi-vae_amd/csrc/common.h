@@ -79,6 +79,7 @@ struct GemmDesc {
     int epi;
     int splitk;     // >=1; >1 requires EPI_ATOMIC
     int unaligned;  // 1: some group base pointer is not 16-B aligned -> scalar global loads
+    int c_aligned;  // 1: every group's C (and aux) base is 16-B aligned (group tables; inline groups are checked)
 };
 
 // groups_dev: device array of ngroups GemmGroup, or nullptr with ngroups==1 and g0 used.

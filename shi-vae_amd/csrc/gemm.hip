@@ -85,7 +85,7 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int s, in
 }
 
 struct GemmParams {
-    int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB;
+    int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB, vecC;
     const GemmGroup* groups;
     GemmGroup g0;
 };
@@ -150,8 +150,75 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
         __syncthreads();
     }
 
-    // epilogue: lanes 0..31 of a half hold 32 consecutive columns of one row -> 128-B row segments
     const int epi = p.epi;
+    constexpr int RP = WM * 32, LDE = BN + 4;  // rows staged per pass, padded row length
+    if constexpr (RP * LDE <= LDS_A + LDS_B) {
+        if (p.vecC) {
+            // Vectorised epilogue: stage one 32-row band of every wave row through LDS, then each thread
+            // handles float4 pieces of whole rows: all aux / old-C loads are issued before the first use
+            // (no per-element round trips) and stores are 16 B per lane, 512 B contiguous per 32 lanes.
+            constexpr int PER = RP * (BN / 4) / NT;
+#pragma unroll
+            for (int x = 0; x < TM; ++x) {
+#pragma unroll
+                for (int y = 0; y < TN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        lds[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDE + (wn * TN + y) * 32 + li] = acc[x][y][r];
+                __syncthreads();
+                constexpr int CH = PER < 2 ? PER : 2;  // float4 pieces in flight per thread (register budget)
+#pragma unroll
+                for (int i0 = 0; i0 < PER; i0 += CH) {
+                    float4 v[CH], cold[CH], ax[CH];
+                    bool ok[CH];
+                    size_t off[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const int f = tid + (i0 + i) * NT, lr = f / (BN / 4), c4 = f % (BN / 4);
+                        const int row = m0 + (lr >> 5) * (TM * 32) + x * 32 + (lr & 31), col = n0 + c4 * 4;
+                        ok[i] = row < p.M && col < p.N;
+                        off[i] = ok[i] ? (size_t)row * p.ldc + col : 0;
+                        v[i] = *reinterpret_cast<const float4*>(lds + lr * LDE + c4 * 4);
+                        if (epi & EPI_ADDC) cold[i] = *reinterpret_cast<const float4*>(g.C + off[i]);
+                        if (epi & EPI_MASK) ax[i] = *reinterpret_cast<const float4*>(g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
+                    }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        if (!ok[i]) continue;
+                        float* cp = g.C + off[i];
+                        float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                        if (epi & EPI_ATOMIC) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) atomicAdd(cp + c, e[c]);
+                            continue;
+                        }
+                        const int col = n0 + ((tid + (i0 + i) * NT) % (BN / 4)) * 4;
+                        if (epi & EPI_BIAS) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) e[c] += g.bias[col + c];
+                        }
+                        if (epi & EPI_ADDC) { e[0] += cold[i].x; e[1] += cold[i].y; e[2] += cold[i].z; e[3] += cold[i].w; }
+                        if (epi & EPI_RELU) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) e[c] = fmaxf(e[c], 0.f);
+                        }
+                        if (epi & EPI_SOFTPLUS) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) e[c] = softplus_f(e[c]);
+                        }
+                        if (epi & EPI_MASK) {
+                            e[0] = ax[i].x > 0.f ? e[0] : 0.f; e[1] = ax[i].y > 0.f ? e[1] : 0.f;
+                            e[2] = ax[i].z > 0.f ? e[2] : 0.f; e[3] = ax[i].w > 0.f ? e[3] : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(cp) = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    // scalar epilogue (unaligned C / ragged N): lanes 0..31 of a half hold 32 consecutive columns of one row
 #pragma unroll
     for (int x = 0; x < TM; ++x)
 #pragma unroll
@@ -239,6 +306,9 @@ int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, con
     p.vecA = (d.lda % 4 == 0) && (extA % 4 == 0) && (groups_dev || aligned16(g0.A));
     p.vecB = (d.ldb % 4 == 0) && (extB % 4 == 0) && (groups_dev || aligned16(g0.B));
     if (d.unaligned) p.vecA = p.vecB = 0;
+    // vector epilogue: whole float4 pieces of C (and aux) rows must be addressable and 16-B aligned
+    p.vecC = (d.ldc % 4 == 0) && (d.N % 4 == 0) && (d.c_aligned || (!groups_dev && aligned16(g0.C))) &&
+             (!(d.epi & EPI_MASK) || (d.ldaux % 4 == 0 && (d.c_aligned || (!groups_dev && aligned16(g0.aux)))));
     switch (d.layout) {
         case GEMM_NT: return launch_layout<true, true>(p, ngroups, stream);
         case GEMM_NN: return launch_layout<true, false>(p, ngroups, stream);

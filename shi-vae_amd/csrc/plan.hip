@@ -54,6 +54,7 @@ struct GroupTable {  // device table of GemmGroup + matching bias-gradient table
     GemmGroup* dev = nullptr;
     int n = 0;
     int unaligned = 0;
+    int c_aligned = 1;
 };
 struct ColTable {
     ColsumGroup* dev = nullptr;
@@ -300,8 +301,12 @@ static int upload(shivae_plan* p, const std::vector<T>& host, T** dev) {
 static int make_table(shivae_plan* p, const std::vector<GemmGroup>& g, GroupTable& t) {
     t.n = (int)g.size();
     t.unaligned = 0;
+    t.c_aligned = 1;
     for (const GemmGroup& x : g)
+    {
         if ((reinterpret_cast<uintptr_t>(x.A) | reinterpret_cast<uintptr_t>(x.B)) & 15) t.unaligned = 1;
+        if ((reinterpret_cast<uintptr_t>(x.C) | reinterpret_cast<uintptr_t>(x.aux)) & 15) t.c_aligned = 0;
+    }
     return upload(p, g, &t.dev);
 }
 static int make_ctable(shivae_plan* p, const std::vector<ColsumGroup>& g, ColTable& t) {
@@ -390,21 +395,30 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
         if (epi == 0 && K >= 4096) {
             // long-K skinny remainder: too few tiles to fill the chip -> zero the columns, split K, add atomically
             SV_CHECK_HIP(hipMemset2DAsync(C + Nm, (size_t)ldc * sizeof(float), 0, (size_t)rem * sizeof(float), M, s));
-            GemmDesc d{layout, M, rem, K, lda, ldb, ldc, 0, EPI_ATOMIC, std::min(32, ceil_div(K, 2048)), 0};
+            GemmDesc d{layout, M, rem, K, lda, ldb, ldc, 0, EPI_ATOMIC, std::min(32, ceil_div(K, 2048)), 0, 0};
             return launch_gemm(d, nullptr, 1, GemmGroup{A, B2, C + Nm, nullptr, nullptr}, s);
         }
         return gemm1(layout, M, rem, K, A, lda, B2, ldb, C + Nm, ldc, bias ? bias + Nm : nullptr,
                      aux ? aux + Nm : nullptr, ldaux, epi, s);
     }
-    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, 0};
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, 0, 0};
     if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, 1);
+    if (epi == 0 && K >= 8192) {
+        // long K but too few output tiles to fill 256 CUs x 4 blocks: zero C, split K, accumulate atomically
+        const int sk = std::min(splitk_for(M, N, K, 1), ceil_div(K, 4096));
+        if (sk > 1) {
+            SV_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+            d.epi = EPI_ATOMIC;
+            d.splitk = sk;
+        }
+    }
     GemmGroup g{A, B, C, bias, aux};
     return launch_gemm(d, nullptr, 1, g, s);
 }
 static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epi, const GroupTable& t,
                  hipStream_t s) {
     if (t.n == 0) return SHIVAE_OK;
-    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned};
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned};
     if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, t.n);
     return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
 }
@@ -836,7 +850,7 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
     SV_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
     SV_REQUIRE(!(epi & EPI_BIAS) || bias, "gemm: bias epilogue without bias");
     SV_REQUIRE(!(epi & EPI_MASK) || aux, "gemm: mask epilogue without aux");
-    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0};
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0, 0};
     GemmGroup g{A, B, C, bias, aux};
     return launch_gemm(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
 }
