@@ -44,6 +44,32 @@ __global__ void unpad_copy_kernel(const float* __restrict__ src, int ld, int col
     }
 }
 
+// out[b][c][r] = in[b][r][c]: batched 2-D transpose through a 32x33 LDS tile (coalesced both ways).
+// Used once per step to keep K-contiguous copies of the decoder weights, so that every input-gradient
+// GEMM runs in the NT form (both operands K-contiguous), which is the fastest layout of gemm.hip.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int C, size_t in_stride, size_t out_stride) {
+    __shared__ float tile[32][33];
+    const float* src = in + blockIdx.z * in_stride;
+    float* dst = out + blockIdx.z * out_stride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(size_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+int launch_transpose(const float* in, float* out, int R, int C, int batch, size_t in_stride, size_t out_stride,
+                     hipStream_t stream) {
+    if (R <= 0 || C <= 0 || batch <= 0) return SHIVAE_OK;
+    SV_REQUIRE(batch <= 65535 && ceil_div(R, 32) <= 65535, "transpose grid too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32), batch), dim3(256), 0, stream, in, out,
+                       R, C, in_stride, out_stride);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
 static int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 16); }
 
 int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, float* embc, int ldc, int rows,

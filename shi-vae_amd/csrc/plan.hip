@@ -220,6 +220,11 @@ static void build_workspace(shivae_plan* p) {
     carve(p, "dhh", Rc * p->ldHH, cur);
     carve(p, "pbuf", Rc * p->P, cur);
     carve(p, "wpack", p->wpack_floats, cur);
+    // K-contiguous (transposed) copies of the decoder weights for the input-gradient GEMMs
+    carve(p, "wt0", (size_t)p->E * D * 2 * H, cur);
+    carve(p, "wt2", D * 2 * H * H, cur);
+    carve(p, "wt4", D * H * H, cur);
+    carve(p, "wth0", (size_t)std::max(p->nbc, 1) * H * H, cur);
     p->ws_bytes = cur;
 }
 
@@ -333,10 +338,10 @@ static int build_tables(shivae_plan* p) {
         fl2.push_back({a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr});
         wl2.push_back({da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr});
         cl2.push_back({da2d, GA(SHIVAE_P_DEC4_B, d)});
-        dl2.push_back({da2d, PA(SHIVAE_P_DEC4_W, d), da1d, nullptr, a1d});
+        dl2.push_back({da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d});
         wl1.push_back({da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr});
         cl1.push_back({da1d, GA(SHIVAE_P_DEC2_B, d)});
-        dl1.push_back({da1d, PA(SHIVAE_P_DEC2_W, d), da0d, nullptr, a0d});
+        dl1.push_back({da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d});
         // heads (decoders.py:69-102)
         float* wout = p->params + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
         float* bout = p->params + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
@@ -351,7 +356,7 @@ static int build_tables(shivae_plan* p) {
             fh0.push_back({a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr});
             wh0.push_back({dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr});
             ch0.push_back({dhhj, GA(SHIVAE_P_HEAD0_B, d)});
-            dh0.push_back({dhhj, PA(SHIVAE_P_HEAD0_W, d), da2d, nullptr, a2d});
+            dh0.push_back({dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d});
             hin = hhj; dhin = dhhj; hmask = hhj;
         }
         // tables are keyed by +nout (input = hh, bin/cat) or -nout (input = a2, real/pos): the two
@@ -461,6 +466,14 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     // 0. scan weights in MFMA operand order (parameters change every optimiser step)
     SV_TRY(launch_pack(p->wjobs_dev, p->n_wjobs, p->bjobs_dev, p->n_bjobs, p->wsf("wpack"), s));
 
+    if (grad) {
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC0_W]), p->wsf("wt0"), D * 2 * H, E, 1, 0, 0, s));
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC2_W]), p->wsf("wt2"), H, 2 * H, D, (size_t)H * 2 * H, (size_t)H * 2 * H, s));
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC4_W]), p->wsf("wt4"), H, H, D, (size_t)H * H, (size_t)H * H, s));
+        if (p->nbc > 0)
+            SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_HEAD0_W]), p->wsf("wth0"), H, H, p->nbc, (size_t)H * H, (size_t)H * H, s));
+    }
+
     // 1. h-independent encoder parts, batched over all T*B rows (encoders.py:82, x/phi_x halves of :83,:91)
     float *p1 = p->wsf("p1"), *phx = p->wsf("phx"), *xs_pre = p->wsf("xs_pre"), *ex_pre = p->wsf("ex_pre");
     SV_TRY(gemm1(NT, R, H, X, x, X, p->prm(g[SHIVAE_P_PHIX0_W]), X, p1, Hp, p->prm(g[SHIVAE_P_PHIX0_B]), nullptr, 0,
@@ -543,18 +556,18 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         }
         SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s));
         SV_TRY(colsumg(rc, H, ldHH, p->c_h0, s));
-        SV_TRY(gemmg(NN, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK, p->b_h0_d, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK, p->b_h0_d, s));
         SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s));
         SV_TRY(colsumg(rc, H, ldA1, p->c_l2, s));
-        SV_TRY(gemmg(NN, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK, p->b_l2_d, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK, p->b_l2_d, s));
         SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s));
         SV_TRY(colsumg(rc, H, ldA1, p->c_l1, s));
-        SV_TRY(gemmg(NN, rc, 2 * H, H, ldA1, 2 * H, ldA0, ldA0, EPI_MASK, p->b_l1_d, s));
+        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK, p->b_l1_d, s));
         // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
         SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                      EPI_ATOMIC, s));
         SV_TRY(colsum1(rc, D * 2 * H, ldA0, da0, p->grd(g[SHIVAE_P_DEC0_B]), s));
-        SV_TRY(gemm1(NN, rc, E, D * 2 * H, da0, ldA0, p->prm(g[SHIVAE_P_DEC0_W]), E, dembc, E4, nullptr, nullptr, 0, 0, s));
+        SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
 
         // ---- prior backward ----
         SV_TRY(gemm1(NN, rc, H, Z, dmupc, Zp, Wpm, H, dprc, Hp, nullptr, nullptr, 0, 0, s));

@@ -22,19 +22,23 @@ def run(layout, M, Nn, K, lda, ldb, ldc, epi=0, splitk=1, iters=5, tag=""):
     ms = e0.elapsed_time(e1) / iters
     print("%-34s layout=%d M=%6d N=%6d K=%6d lda=%7d ldb=%7d  %8.3f ms  %6.1f TF" % (tag, layout, M, Nn, K, lda, ldb, ms, 2.0*M*Nn*K/ms/1e9), flush=True)
 
-R = 16384
-run(0, R, 512, 528, 528, 528, 512, tag="NT contiguous")
-run(0, R, 4096, 528, 528, 528, 4096, tag="NT wide N")
-run(0, R, 256, 512, 512, 512, 256, tag="NT L1 contiguous")
-run(0, R, 256, 512, 131072, 512, 65536, tag="NT L1 lda=131072 (pow2)")
-run(0, R, 256, 512, 131072 + 64, 512, 65536 + 64, tag="NT L1 lda padded")
-run(0, 4096, 4096, 4096, 4096, 4096, 4096, tag="NT 4096^3")
-run(1, R, 512, 256, 256, 512, 512, tag="NN dL1 contiguous")
-run(1, R, 512, 256, 65536, 512, 131072, tag="NN dL1 pow2 ld")
-run(1, R, 512, 256, 65536 + 64, 512, 131072 + 64, tag="NN dL1 padded ld")
-run(1, R, 528, 8192, 8192, 528, 528, tag="NN dL0 K=8192")
-run(1, 4096, 4096, 4096, 4096, 4096, 4096, tag="NN 4096^3")
-run(2, 512, 528, R, 512, 528, 528, epi=32, splitk=8, tag="TN wgrad splitk8")
-run(2, 256, 512, R, 65536, 131072, 512, epi=32, splitk=8, tag="TN wL1 pow2 ld")
-run(2, 256, 512, R, 65536 + 64, 131072 + 64, 512, epi=32, splitk=8, tag="TN wL1 padded ld")
-run(2, 4096, 4096, 4096, 4096, 4096, 4096, tag="TN 4096^3")
+def main():
+    R = 16384
+    run(0, R, 512, 528, 528, 528, 512, tag="NT contiguous")
+    run(0, R, 4096, 528, 528, 528, 4096, tag="NT wide N")
+    run(0, R, 256, 512, 512, 512, 256, tag="NT L1 contiguous")
+    run(0, R, 256, 512, 131072, 512, 65536, tag="NT L1 lda=131072 (pow2)")
+    run(0, R, 256, 512, 131072 + 64, 512, 65536 + 64, tag="NT L1 lda padded")
+    run(0, 4096, 4096, 4096, 4096, 4096, 4096, tag="NT 4096^3")
+    run(1, R, 512, 256, 256, 512, 512, tag="NN dL1 contiguous")
+    run(1, R, 512, 256, 65536, 512, 131072, tag="NN dL1 pow2 ld")
+    run(1, R, 512, 256, 65536 + 64, 512, 131072 + 64, tag="NN dL1 padded ld")
+    run(1, R, 528, 8192, 8192, 528, 528, tag="NN dL0 K=8192")
+    run(1, 4096, 4096, 4096, 4096, 4096, 4096, tag="NN 4096^3")
+    run(2, 512, 528, R, 512, 528, 528, epi=32, splitk=8, tag="TN wgrad splitk8")
+    run(2, 256, 512, R, 65536, 131072, 512, epi=32, splitk=8, tag="TN wL1 pow2 ld")
+    run(2, 256, 512, R, 65536 + 64, 131072 + 64, 512, epi=32, splitk=8, tag="TN wL1 padded ld")
+    run(2, 4096, 4096, 4096, 4096, 4096, 4096, tag="TN 4096^3")
+
+if __name__ == "__main__":
+    main()
