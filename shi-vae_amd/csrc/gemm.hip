@@ -90,12 +90,14 @@ struct GemmParams {
     GemmGroup g0;
 };
 
-template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_kernel(GemmParams p) {
+template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int WPE, bool DB>
+__global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
+    static_assert(WM * WN <= 8, "at most 8 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int LDS_A = A_KC ? BM * 36 : 32 * BM;
     constexpr int LDS_B = B_KC ? BN * 36 : 32 * BN;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_A + LDS_B];
+    constexpr int STAGE = LDS_A + LDS_B;
+    __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * STAGE];
     float* ldsA = lds;
     float* ldsB = lds + LDS_A;
 
@@ -118,25 +120,14 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
 
     TileLoader<A_KC, BM, NT, VEC> la;
     TileLoader<B_KC, BN, NT, VEC> lb;
-    if (kbeg < kend) {
-        la.load(g.A, p.lda, m0, p.M, kbeg, kend, tid);
-        lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        la.store(ldsA, tid);
-        lb.store(ldsB, tid);
-        __syncthreads();
-        if (k0 + 32 < kend) {
-            la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
-            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
-        }
+    auto compute = [&](const float* sa, const float* sb) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float4 a[TM], b[TN];
 #pragma unroll
-            for (int x = 0; x < TM; ++x) a[x] = read_frag<A_KC, BM>(ldsA, (wm * TM + x) * 32 + li, s, lh);
+            for (int x = 0; x < TM; ++x) a[x] = read_frag<A_KC, BM>(sa, (wm * TM + x) * 32 + li, s, lh);
 #pragma unroll
-            for (int y = 0; y < TN; ++y) b[y] = read_frag<B_KC, BN>(ldsB, (wn * TN + y) * 32 + li, s, lh);
+            for (int y = 0; y < TN; ++y) b[y] = read_frag<B_KC, BN>(sb, (wn * TN + y) * 32 + li, s, lh);
 #pragma unroll
             for (int x = 0; x < TM; ++x)
 #pragma unroll
@@ -147,40 +138,110 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].w, b[y].w, acc[x][y], 0, 0, 0);
                 }
         }
+    };
+    if (kbeg < kend) {
+        la.load(g.A, p.lda, m0, p.M, kbeg, kend, tid);
+        lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid);
+    }
+    if constexpr (DB) {
+        // two LDS stages, one barrier per K-tile: the next tile's registers are parked in the other
+        // stage after this tile's MFMAs, so the global-load latency hides behind them
+        la.store(ldsA, tid);
+        lb.store(ldsB, tid);
         __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            const bool more = k0 + 32 < kend;
+            if (more) {
+                la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
+                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+            }
+            compute(ldsA + cur * STAGE, ldsB + cur * STAGE);
+            if (more) {
+                la.store(ldsA + (cur ^ 1) * STAGE, tid);
+                lb.store(ldsB + (cur ^ 1) * STAGE, tid);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            la.store(ldsA, tid);
+            lb.store(ldsB, tid);
+            __syncthreads();
+            if (k0 + 32 < kend) {
+                la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
+                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+            }
+            compute(ldsA, ldsB);
+            __syncthreads();
+        }
     }
 
     const int epi = p.epi;
-    constexpr int RP = WM * 32, LDE = BN + 4;  // rows staged per pass, padded row length
-    if constexpr (RP * LDE <= LDS_A + LDS_B) {
+    constexpr int LDE = BN + 4;                              // padded row length of the staged tile
+    constexpr int BANDS = WM * TM;                           // 32-row bands of the block tile
+    constexpr int GMAX = (DB ? 2 : 1) * STAGE / (32 * LDE);       // bands that fit in LDS at once
+    constexpr int G = GMAX >= BANDS ? BANDS : (GMAX >= 4 ? 4 : (GMAX >= 2 ? 2 : (GMAX >= 1 ? 1 : 0)));
+    if constexpr (G > 0 && BANDS % (G > 0 ? G : 1) == 0 && (G * 32 * (BN / 4)) % NT == 0) {
         if (p.vecC) {
-            // Vectorised epilogue: stage one 32-row band of every wave row through LDS, then each thread
-            // handles float4 pieces of whole rows: all aux / old-C loads are issued before the first use
-            // (no per-element round trips) and stores are 16 B per lane, 512 B contiguous per 32 lanes.
-            constexpr int PER = RP * (BN / 4) / NT;
+            // Vectorised epilogue: stage G 32-row bands through LDS, then each thread handles float4
+            // pieces of whole rows (16 B per lane, 512 B contiguous per 32 lanes).  A thread's pieces all
+            // sit in the same 4 columns, so its bias is loaded once; the ReLU-gate activations of a whole
+            // pass are requested BEFORE the staging barrier (the stores to C may alias them as far as the
+            // compiler knows, so it cannot hoist these loads itself and would pay one memory round trip
+            // per piece).
+            constexpr int PER = G * 32 * (BN / 4) / NT;
+            constexpr int CH = PER < 2 ? PER : 2;  // float4 pieces of old C in flight per thread
+            constexpr bool PF = TM * TN <= 2;      // registers for the whole pass's gate loads (else per round)
+            static_assert(NT % (BN / 4) == 0, "a thread keeps its columns across pieces");
+            const int c4 = tid % (BN / 4), col = n0 + c4 * 4;
+            const bool colok = col < p.N;
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((epi & EPI_BIAS) && colok) {
 #pragma unroll
-            for (int x = 0; x < TM; ++x) {
+                for (int c = 0; c < 4; ++c) bias4[c] = g.bias[col + c];
+            }
 #pragma unroll
-                for (int y = 0; y < TN; ++y)
+            for (int pi = 0; pi < BANDS / G; ++pi) {
+                float4 ax[PER];
+                if (PF && (epi & EPI_MASK)) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        lds[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDE + (wn * TN + y) * 32 + li] = acc[x][y][r];
+                    for (int i = 0; i < PER; ++i) {
+                        const int lr = (tid + i * NT) / (BN / 4);
+                        const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
+                        ax[i] = *reinterpret_cast<const float4*>(
+                            g.aux + ((colok && row < p.M) ? (size_t)row * p.ldaux + col : 0));
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < TM; ++x) {
+                    const int band = wm * TM + x;
+                    if (band / G == pi) {
+#pragma unroll
+                        for (int y = 0; y < TN; ++y)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                lds[((band % G) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDE + (wn * TN + y) * 32 + li] =
+                                    acc[x][y][r];
+                    }
+                }
                 __syncthreads();
-                constexpr int CH = PER < 2 ? PER : 2;  // float4 pieces in flight per thread (register budget)
 #pragma unroll
                 for (int i0 = 0; i0 < PER; i0 += CH) {
-                    float4 v[CH], cold[CH], ax[CH];
+                    float4 v[CH], cold[CH];
                     bool ok[CH];
                     size_t off[CH];
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
-                        const int f = tid + (i0 + i) * NT, lr = f / (BN / 4), c4 = f % (BN / 4);
-                        const int row = m0 + (lr >> 5) * (TM * 32) + x * 32 + (lr & 31), col = n0 + c4 * 4;
-                        ok[i] = row < p.M && col < p.N;
+                        const int lr = (tid + (i0 + i) * NT) / (BN / 4);
+                        const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
+                        ok[i] = colok && row < p.M;
                         off[i] = ok[i] ? (size_t)row * p.ldc + col : 0;
                         v[i] = *reinterpret_cast<const float4*>(lds + lr * LDE + c4 * 4);
                         if (epi & EPI_ADDC) cold[i] = *reinterpret_cast<const float4*>(g.C + off[i]);
-                        if (epi & EPI_MASK) ax[i] = *reinterpret_cast<const float4*>(g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
+                        if (!PF && (epi & EPI_MASK))
+                            ax[i0 + i] = *reinterpret_cast<const float4*>(g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
                     }
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
@@ -192,11 +253,8 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
                             for (int c = 0; c < 4; ++c) atomicAdd(cp + c, e[c]);
                             continue;
                         }
-                        const int col = n0 + ((tid + (i0 + i) * NT) % (BN / 4)) * 4;
-                        if (epi & EPI_BIAS) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) e[c] += g.bias[col + c];
-                        }
+                        for (int c = 0; c < 4; ++c) e[c] += bias4[c];
                         if (epi & EPI_ADDC) { e[0] += cold[i].x; e[1] += cold[i].y; e[2] += cold[i].z; e[3] += cold[i].w; }
                         if (epi & EPI_RELU) {
 #pragma unroll
@@ -207,13 +265,14 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
                             for (int c = 0; c < 4; ++c) e[c] = softplus_f(e[c]);
                         }
                         if (epi & EPI_MASK) {
-                            e[0] = ax[i].x > 0.f ? e[0] : 0.f; e[1] = ax[i].y > 0.f ? e[1] : 0.f;
-                            e[2] = ax[i].z > 0.f ? e[2] : 0.f; e[3] = ax[i].w > 0.f ? e[3] : 0.f;
+                            const float4 a4 = ax[i0 + i];
+                            e[0] = a4.x > 0.f ? e[0] : 0.f; e[1] = a4.y > 0.f ? e[1] : 0.f;
+                            e[2] = a4.z > 0.f ? e[2] : 0.f; e[3] = a4.w > 0.f ? e[3] : 0.f;
                         }
                         *reinterpret_cast<float4*>(cp) = make_float4(e[0], e[1], e[2], e[3]);
                     }
                 }
-                __syncthreads();
+                if (pi + 1 < BANDS / G) __syncthreads();
             }
             return;
         }
@@ -248,18 +307,19 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN <= 4 ? 4 : 2)) void gemm_ker
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN>
+template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int MINB = (TM * TN <= 2 ? 4 : (TM * TN <= 4 ? 3 : 2)), bool DB = false>
 static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int layout = A_KC ? (B_KC ? GEMM_NT : GEMM_NN) : GEMM_TN;
     constexpr int tile = (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
                        : (BM == 64 && BN == 256) ? 3 : (BM == 128 && BN == 128) ? 4 : 5;
+    (void)tile;
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
     SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
                ngroups, p.splitk);
     prof_shape(p.M, p.N, p.K, ngroups);
     prof_begin(layout * 6 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
-    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN, MINB, DB>), grid, dim3(WM * WN * 64), 0, stream, p);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
@@ -272,11 +332,11 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     if (p.M <= 32) return launch_cfg<A_KC, B_KC, VEC, 1, 4, 1, 2>(p, ngroups, stream);   // 32 x 256
     if (p.N <= 64) return launch_cfg<A_KC, B_KC, VEC, 4, 1, 2, 2>(p, ngroups, stream);   // 256 x 64
     if (p.M <= 64) return launch_cfg<A_KC, B_KC, VEC, 1, 4, 2, 2>(p, ngroups, stream);   // 64 x 256
-    const char* force = getenv("SHIVAE_GEMM_TILE");
-    const int mode = force ? atoi(force) : 0;
-    if (mode == 1)
-        return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 4>(p, ngroups, stream);               // 128 x 256
-    return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2>(p, ngroups, stream);                  // 128 x 128
+    // default: 128 x 128 on 8 waves (32 x 64 per wave: no spills at 4 waves/SIMD) with two LDS stages.
+    // SHIVAE_GEMM_TILE selects the other measured variants (tools/gemm_bench.py).
+    static const int mode = [] { const char* f = getenv("SHIVAE_GEMM_TILE"); return f ? atoi(f) : 0; }();
+    if (mode == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false>(p, ngroups, stream);  // 8 waves, 1 stage
+    return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, true>(p, ngroups, stream);                  // 128 x 128, 8 waves
 }
 
 template <bool A_KC, bool B_KC>

@@ -388,6 +388,22 @@ static int splitk_for(int M, int N, int K, int groups) {
     return std::max(sk, 1);
 }
 
+// Split of a long K for a GEMM with few output tiles: the smallest split whose blocks fill whole rounds of
+// the chip's 512 resident workgroups (256 CUs x 2) to >= 92 %, K chunks of at least min_chunk.
+static int splitk_fill(int M, int N, int K, int min_chunk) {
+    const int tiles = ceil_div(M, 128) * ceil_div(N, 128);
+    const int max_sk = std::max(1, std::min(K / min_chunk, 64));
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sk = 1; sk <= max_sk; ++sk) {
+        const int blocks = tiles * sk;
+        const double eff = (double)blocks / ((double)ceil_div(blocks, 512) * 512.0);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = sk; }
+        if (eff >= 0.92) break;
+    }
+    return best;
+}
+
 static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                  const float* bias, const float* aux, int ldaux, int epi, hipStream_t s) {
     // A few columns past a multiple of 128 (E = 2H+K = 528 at H=256, K=16) would cost a whole extra
@@ -410,7 +426,7 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
     if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, 1);
     if (epi == 0 && K >= 8192) {
         // long K but too few output tiles to fill 256 CUs x 4 blocks: zero C, split K, accumulate atomically
-        const int sk = std::min(splitk_for(M, N, K, 1), ceil_div(K, 4096));
+        const int sk = splitk_fill(M, N, K, 4096);
         if (sk > 1) {
             SV_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
             d.epi = EPI_ATOMIC;
