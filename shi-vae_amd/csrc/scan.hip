@@ -22,6 +22,9 @@
 //     wave that owns hidden units [16*ht, 16*ht+16) computes all four gates of those units.
 // Feature dims are padded to multiples of 16 (H->Hp, Z->Zp, K->Kp) with zero weights/biases, which
 // keeps every padded lane at exactly 0 through ReLU, the LSTM cell (c=0 -> h=0) and the gradients.
+#include <algorithm>
+#include <cstdlib>
+
 #include "cell_math.h"
 #include "common.h"
 
@@ -86,8 +89,13 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f),
 __device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0.f ? v[0] : 0.f, a[1] > 0.f ? v[1] : 0.f, a[2] > 0.f ? v[2] : 0.f, a[3] > 0.f ? v[3] : 0.f}; }
 
 // ---------------------------------------------------------------------------------- forward
-template <int MAXS>
-__global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
+// Per timestep the serial chain is  a_s -> logits -> s -> e1 -> e2 -> (mu,std,z) -> phi_z -> gates.
+// Everything that needs only h_{t-1} (the h halves of a_s and e1, Whh h_{t-1}: half of the MFMA work)
+// is issued in the first two phases, where it overlaps the one-wave logits/Gumbel-softmax stage; the
+// operands that do not depend on the recurrence (xs_pre, ex_pre, eps, u) are requested at the top of
+// the step so their HBM latency is off the chain.  A wave owns hidden tiles ht = wid + s*NW, s < MAXS.
+template <int MAXS, int NTH>
+__global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -103,11 +111,18 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
     float* lgbuf = sbuf + Kp * 16;
     float* zbuf = lgbuf + Kp * 16;
     const float* Wb = a.wpack;
+    const f32x4 zero4 = {0, 0, 0, 0};
 
     for (int i = tid; i < Hp * 16; i += blockDim.x) hb0[i] = 0.f;  // shivae.py:93 h0 = 0
     f32x4 creg[MAXS];
+    int own[MAXS];      // owned hidden tile (clamped), valid if ownok
+    bool ownok[MAXS];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) creg[s] = f32x4{0, 0, 0, 0};  // shivae.py:94 c0 = 0
+    for (int s = 0; s < MAXS; ++s) {
+        creg[s] = zero4;  // shivae.py:94 c0 = 0
+        ownok[s] = wid + s * NW < HT;
+        own[s] = ownok[s] ? wid + s * NW : 0;
+    }
     __syncthreads();
 
     int cur = 0;
@@ -116,89 +131,173 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
         const float* h = cur ? hb1 : hb0;
         float* hn = cur ? hb0 : hb1;
 
-        // S1: a_s = relu(xs_pre + Wxs0[:, X:] h)          encoders.py:83 (x half hoisted)
+        // operands independent of the recurrence: request now, use later
+        f32x4 xs_pf[MAXS], ex_pf[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const bool ld = live && ownok[s];
+            xs_pf[s] = ld ? ld4(a.xs_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
+            ex_pf[s] = ld ? ld4(a.ex_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
+        }
+        float eps_pf[4] = {0.f, 0.f, 0.f, 0.f}, u_pf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+        if (wid < ZT && live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wid * 16 + 4 * q + r;
+                if (n < a.Z) eps_pf[r] = a.eps[row * a.Z + n];
+            }
+        }
+        if (wid == 0 && KT == 1 && live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < a.K) u_pf[r] = a.u[row * a.K + 4 * q + r];
+        }
+
+        // P0: a_s = relu(xs_pre + Wxs0[:, X:] h)   encoders.py:83 (x half hoisted);  e1 partial = We0[:, H+K:] h
+        f32x4 e1acc[MAXS];
         {
-            const Src src[1] = {{Wb + a.w.xsh, h, HT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                if (live) v += ld4(a.xs_pre + row * Hp + n);
-                v = relu4(v);
-                st4(bufA + qidx(nt, q, j), v);
-                if (live) st4(a.as_ + row * Hp + n, v);
-            });
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) { acc[s] = zero4; e1acc[s] = zero4; }
+            mma_acc<MAXS>(acc, Wb + a.w.xsh, HT, own, h, lane);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const f32x4 v = relu4(acc[s] + xs_pf[s]);
+                    st4(bufA + qidx(own[s], q, j), v);
+                    if (live) st4(a.as_ + row * Hp + own[s] * 16 + 4 * q, v);
+                }
+            mma_acc<MAXS>(e1acc, Wb + a.w.e0h, HT, own, h, lane);
         }
         __syncthreads();
-        // S2: s logits = LeakyReLU(Wxs2 a_s + b)           encoders.py:56-57
-        {
-            const Src src[1] = {{Wb + a.w.lg, bufA, HT}};
-            layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                v += ld4(Wb + a.w.b_lg + nt * 16 + 4 * q);
-                st4(lgbuf + qidx(nt, q, j), f32x4{sv_leaky(v[0]), sv_leaky(v[1]), sv_leaky(v[2]), sv_leaky(v[3])});
-            });
-        }
-        __syncthreads();
-        // S3: s_probs = softmax(logits); s = softmax((logits + gumbel(u)) / temp)   encoders.py:87-88
-        if (tid < 16) {
-            const int jj = tid, bb = blockIdx.x * 16 + jj;
-            const bool lv = bb < B;
-            const size_t r = (size_t)t * B + (lv ? bb : 0);
-            float m1 = -INFINITY, m2 = -INFINITY;
-            for (int k = 0; k < a.K; ++k) {
-                const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                const float u = lv ? a.u[r * a.K + k] : 0.5f;
-                m1 = fmaxf(m1, l);
-                m2 = fmaxf(m2, (l + sv_gumbel(u)) / a.temp);
+        // P1: s logits = LeakyReLU(Wxs2 a_s + b) (encoders.py:56-57); s_probs = softmax(logits),
+        //     s = softmax((logits + gumbel(u)) / temp) (encoders.py:87-88, samplers.py:23-30)
+        if (KT == 1) {
+            // K <= 16: the logits tile of wave 0 has k = 4q+r in lane (q, j): softmax over k is an in-lane
+            // reduction over r plus two xor-shuffles over q -- no LDS round trip, no extra barrier
+            if (wid == 0) {
+                const int nt0[1] = {0};
+                f32x4 lg[1] = {zero4};
+                mma_acc<1>(lg, Wb + a.w.lg, HT, nt0, bufA, lane);
+                const f32x4 bl = ld4(Wb + a.w.b_lg + 4 * q);
+                float l[4], y[4], m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kv = 4 * q + r < a.K;
+                    l[r] = sv_leaky(lg[0][r] + bl[r]);
+                    y[r] = (l[r] + sv_gumbel(u_pf[r])) / a.temp;
+                    if (kv) { m1 = fmaxf(m1, l[r]); m2 = fmaxf(m2, y[r]); }
+                }
+                m1 = fmaxf(m1, __shfl_xor(m1, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                m2 = fmaxf(m2, __shfl_xor(m2, 16)); m2 = fmaxf(m2, __shfl_xor(m2, 32));
+                float e1v[4], e2v[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kv = 4 * q + r < a.K;
+                    e1v[r] = kv ? expf(l[r] - m1) : 0.f;
+                    e2v[r] = kv ? expf(y[r] - m2) : 0.f;
+                    s1 += e1v[r]; s2 += e2v[r];
+                }
+                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                f32x4 pv, sv, lv4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = e1v[r] / s1; sv[r] = e2v[r] / s2;
+                    lv4[r] = 4 * q + r < a.K ? l[r] : 0.f;
+                }
+                st4(sbuf + qidx(0, q, j), sv);
+                if (live) {
+                    st4(a.logits + row * Kp + 4 * q, lv4);
+                    st4(a.probs + row * Kp + 4 * q, pv);
+                    st4(a.emb + row * Ep + Hp + 4 * q, sv);
+                }
             }
-            float s1 = 0.f, s2 = 0.f;
-            for (int k = 0; k < a.K; ++k) {
-                const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                const float u = lv ? a.u[r * a.K + k] : 0.5f;
-                s1 += expf(l - m1);
-                s2 += expf((l + sv_gumbel(u)) / a.temp - m2);
+        } else {
+            {
+                const Src src[1] = {{Wb + a.w.lg, bufA, HT}};
+                layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                    v += ld4(Wb + a.w.b_lg + nt * 16 + 4 * q);
+                    st4(lgbuf + qidx(nt, q, j), f32x4{sv_leaky(v[0]), sv_leaky(v[1]), sv_leaky(v[2]), sv_leaky(v[3])});
+                });
             }
-            for (int k = 0; k < Kp; ++k) {
-                float sv = 0.f;
-                if (k < a.K) {
+            __syncthreads();
+            if (tid < 16) {
+                const int jj = tid, bb = blockIdx.x * 16 + jj;
+                const bool lv = bb < B;
+                const size_t r = (size_t)t * B + (lv ? bb : 0);
+                float m1 = -INFINITY, m2 = -INFINITY;
+                for (int k = 0; k < a.K; ++k) {
                     const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
                     const float u = lv ? a.u[r * a.K + k] : 0.5f;
-                    sv = expf((l + sv_gumbel(u)) / a.temp - m2) / s2;
-                    if (lv) {
-                        a.logits[r * Kp + k] = l;
-                        a.probs[r * Kp + k] = expf(l - m1) / s1;
-                        a.emb[r * Ep + Hp + k] = sv;
-                    }
+                    m1 = fmaxf(m1, l);
+                    m2 = fmaxf(m2, (l + sv_gumbel(u)) / a.temp);
                 }
-                sbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = sv;
+                float s1 = 0.f, s2 = 0.f;
+                for (int k = 0; k < a.K; ++k) {
+                    const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                    const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                    s1 += expf(l - m1);
+                    s2 += expf((l + sv_gumbel(u)) / a.temp - m2);
+                }
+                for (int k = 0; k < Kp; ++k) {
+                    float sv = 0.f;
+                    if (k < a.K) {
+                        const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                        const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                        sv = expf((l + sv_gumbel(u)) / a.temp - m2) / s2;
+                        if (lv) {
+                            a.logits[r * Kp + k] = l;
+                            a.probs[r * Kp + k] = expf(l - m1) / s1;
+                            a.emb[r * Ep + Hp + k] = sv;
+                        }
+                    }
+                    sbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = sv;
+                }
             }
         }
+        //     meanwhile, off the chain: LSTM gate partials Whh h_{t-1} (gate order i,f,g,o; shivae.py:136)
+        f32x4 g4[MAXS][4];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int nt[4] = {own[s], HT + own[s], 2 * HT + own[s], 3 * HT + own[s]};
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) g4[s][gi] = zero4;
+            if (ownok[s]) mma_acc<4>(g4[s], Wb + a.w.hh, HT, nt, h, lane);
+        }
         __syncthreads();
-        // S4: e1 = relu(ex_pre + We0[:, H:H+K] s + We0[:, H+K:] h)    encoders.py:91 (phi_x part hoisted)
+        // P2: e1 = relu(ex_pre + We0[:, H:H+K] s + We0[:, H+K:] h)    encoders.py:91 (phi_x part hoisted)
         {
-            const Src src[2] = {{Wb + a.w.e0s, sbuf, KT}, {Wb + a.w.e0h, h, HT}};
-            layer<2>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                if (live) v += ld4(a.ex_pre + row * Hp + n);
-                v = relu4(v);
-                st4(bufB + qidx(nt, q, j), v);
-                if (live) st4(a.e1 + row * Hp + n, v);
-            });
+            mma_acc<MAXS>(e1acc, Wb + a.w.e0s, KT, own, sbuf, lane);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const f32x4 v = relu4(e1acc[s] + ex_pf[s]);
+                    st4(bufB + qidx(own[s], q, j), v);
+                    if (live) st4(a.e1 + row * Hp + own[s] * 16 + 4 * q, v);
+                }
         }
         __syncthreads();
         // S5: e2 = relu(We2 e1 + b)                         encoders.py:63-64
         {
-            const Src src[1] = {{Wb + a.w.e2, bufB, HT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                v = relu4(v + ld4(Wb + a.w.b_e2 + n));
-                st4(bufA + qidx(nt, q, j), v);
-                if (live) st4(a.e2 + row * Hp + n, v);
-            });
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.e2, HT, own, bufB, lane);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const int n = own[s] * 16 + 4 * q;
+                    const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_e2 + n));
+                    st4(bufA + qidx(own[s], q, j), v);
+                    if (live) st4(a.e2 + row * Hp + n, v);
+                }
         }
         __syncthreads();
         // S6: mu, std = softplus(.), z = eps*std + mu       encoders.py:93-96, samplers.py:57-62
         for (int zt = wid; zt < ZT; zt += NW) {
             const int nt[1] = {zt};
-            f32x4 am[1] = {{0, 0, 0, 0}}, as[1] = {{0, 0, 0, 0}};
+            f32x4 am[1] = {zero4}, as[1] = {zero4};
             mma_acc<1>(am, Wb + a.w.mu, HT, nt, bufA, lane);
             mma_acc<1>(as, Wb + a.w.sd, HT, nt, bufA, lane);
             const int n = zt * 16 + 4 * q;
@@ -208,7 +307,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sd[r] = sv_softplus(sp[r]);
-                const float e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
+                float e = eps_pf[r];
+                if (zt != wid) e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
                 z[r] = e * sd[r] + mu[r];
             }
             st4(zbuf + qidx(zt, q, j), z);
@@ -221,34 +321,37 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
         __syncthreads();
         // S7: phi_z = relu(Wz z + b)                        shivae.py:132
         {
-            const Src src[1] = {{Wb + a.w.pz, zbuf, ZT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                v = relu4(v + ld4(Wb + a.w.b_pz + n));
-                st4(bufB + qidx(nt, q, j), v);
-                if (live) st4(a.emb + row * Ep + n, v);
-            });
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.pz, ZT, own, zbuf, lane);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const int n = own[s] * 16 + 4 * q;
+                    const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_pz + n));
+                    st4(bufB + qidx(own[s], q, j), v);
+                    if (live) st4(a.emb + row * Ep + n, v);
+                }
         }
         __syncthreads();
-        // S8: LSTM cell (gate order i,f,g,o), c in registers  shivae.py:136
+        // S8: LSTM cell, c in registers                      shivae.py:136
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
-            const int ht = wid + s * NW;
-            if (ht < HT) {
+            if (ownok[s]) {
+                const int ht = own[s];
                 const int nt[4] = {ht, HT + ht, 2 * HT + ht, 3 * HT + ht};
-                f32x4 g4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-                mma_acc<4>(g4, Wb + a.w.ih, HT, nt, bufB, lane);
-                mma_acc<4>(g4, Wb + a.w.hh, HT, nt, h, lane);
+                mma_acc<4>(g4[s], Wb + a.w.ih, HT, nt, bufB, lane);
                 const int n = ht * 16 + 4 * q;
 #pragma unroll
-                for (int gidx = 0; gidx < 4; ++gidx) g4[gidx] += ld4(Wb + a.w.b_g + gidx * Hp + n);
+                for (int gidx = 0; gidx < 4; ++gidx) g4[s][gidx] += ld4(Wb + a.w.b_g + gidx * Hp + n);
                 f32x4 gi, gf, gg, go, cn, hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    gi[r] = sv_sigmoid(g4[0][r]);
-                    gf[r] = sv_sigmoid(g4[1][r]);
-                    gg[r] = tanhf(g4[2][r]);
-                    go[r] = sv_sigmoid(g4[3][r]);
+                    gi[r] = sv_sigmoid(g4[s][0][r]);
+                    gf[r] = sv_sigmoid(g4[s][1][r]);
+                    gg[r] = tanhf(g4[s][2][r]);
+                    go[r] = sv_sigmoid(g4[s][3][r]);
                     cn[r] = gf[r] * creg[s][r] + gi[r] * gg[r];
                     hv[r] = go[r] * tanhf(cn[r]);
                 }
@@ -269,8 +372,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------- backward
-template <int MAXS>
-__global__ __launch_bounds__(256) void scan_bwd_kernel(ScanArgs a) {
+template <int MAXS, int NTH>
+__global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -512,22 +615,27 @@ int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int 
 
 // ---------------------------------------------------------------------------------- launch
 static int scan_geometry(const ScanArgs& a, int& nw, int& maxs) {
+    // waves per workgroup: one per 16 hidden units up to 16 waves (4 per SIMD hide the L2 latency of
+    // the streamed weights); each wave keeps ceil(HT/nw) cell-state tiles in registers
     const int HT = a.Hp / 16;
-    nw = HT >= 4 ? 4 : (HT >= 2 ? 2 : 1);
+    nw = 1;
+    while (nw * 2 <= HT && nw < 16) nw *= 2;
+    static const int force = [] { const char* f = getenv("SHIVAE_SCAN_WAVES"); return f ? atoi(f) : 0; }();
+    if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) nw = std::min(nw, force);
     const int need = ceil_div(HT, nw);
     maxs = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
-    SV_REQUIRE(need <= 8, "scan: h_dim %d too large for the register-resident cell (max 512)", a.H);
+    SV_REQUIRE(need <= 8, "scan: h_dim %d too large for the register-resident cell", a.H);
     return SHIVAE_OK;
 }
 
 size_t scan_fwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (4 * a.Hp + 2 * a.Kp + a.Zp); }
 size_t scan_bwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (7 * a.Hp + 2 * a.Kp + 2 * a.Zp); }
 
-template <int MAXS>
+template <int MAXS, int NTH>
 static int launch_scan_t(const ScanArgs& a, bool bwd, int nw, hipStream_t stream) {
     const size_t lds = bwd ? scan_bwd_lds_bytes(a) : scan_fwd_lds_bytes(a);
     SV_REQUIRE(lds <= 160 * 1024, "scan: needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = bwd ? scan_bwd_kernel<MAXS> : scan_fwd_kernel<MAXS>;
+    auto kern = bwd ? scan_bwd_kernel<MAXS, NTH> : scan_fwd_kernel<MAXS, NTH>;
     if (lds > 64 * 1024)
         SV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -540,11 +648,30 @@ int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream) {
     if (a.T <= 0 || a.B <= 0) return SHIVAE_OK;
     int nw, maxs;
     SV_TRY(scan_geometry(a, nw, maxs));
+    if (nw == 8) {
+        switch (maxs) {
+            case 1: return launch_scan_t<1, 512>(a, bwd, nw, stream);
+            case 2: return launch_scan_t<2, 512>(a, bwd, nw, stream);
+            case 4: return launch_scan_t<4, 512>(a, bwd, nw, stream);
+            default: break;
+        }
+        set_error("scan: unsupported geometry nw=%d maxs=%d", nw, maxs);
+        return SHIVAE_ERR_INVALID;
+    }
+    if (nw > 4) {
+        switch (maxs) {
+            case 1: return launch_scan_t<1, 1024>(a, bwd, nw, stream);
+            case 2: return launch_scan_t<2, 1024>(a, bwd, nw, stream);
+            default: break;
+        }
+        set_error("scan: unsupported geometry nw=%d maxs=%d", nw, maxs);
+        return SHIVAE_ERR_INVALID;
+    }
     switch (maxs) {
-        case 1: return launch_scan_t<1>(a, bwd, nw, stream);
-        case 2: return launch_scan_t<2>(a, bwd, nw, stream);
-        case 4: return launch_scan_t<4>(a, bwd, nw, stream);
-        default: return launch_scan_t<8>(a, bwd, nw, stream);
+        case 1: return launch_scan_t<1, 256>(a, bwd, nw, stream);
+        case 2: return launch_scan_t<2, 256>(a, bwd, nw, stream);
+        case 4: return launch_scan_t<4, 256>(a, bwd, nw, stream);
+        default: return launch_scan_t<8, 256>(a, bwd, nw, stream);
     }
 }
 

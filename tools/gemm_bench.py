@@ -6,15 +6,17 @@ from shivae_amd import _native as N
 
 L = N.lib()
 
-def run(layout, M, Nn, K, lda, ldb, ldc, epi=0, splitk=1, iters=5, tag=""):
+def run(layout, M, Nn, K, lda, ldb, ldc, epi=0, splitk=1, iters=5, tag="", warm=1):
     rowsA = M if layout != 2 else K
     rowsB = Nn if layout == 0 else K
     A = torch.randn(rowsA, lda, device="cuda")
     B = torch.randn(rowsB, ldb, device="cuda")
     C = torch.zeros(M, ldc, device="cuda")
+    bias = torch.randn(Nn, device="cuda") if epi & 1 else None
     def go():
-        N.check(L.shivae_gemm(layout, M, Nn, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C), ldc, None, None, 0, epi, splitk, N.stream()))
-    go(); torch.cuda.synchronize()
+        N.check(L.shivae_gemm(layout, M, Nn, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C), ldc, N.ptr(bias) if epi & 1 else None, None, 0, epi, splitk, N.stream()))
+    for _ in range(warm): go()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): go()
