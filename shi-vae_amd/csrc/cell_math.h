@@ -20,6 +20,32 @@ __device__ __forceinline__ float sv_leaky(float v) { return v > 0.f ? v : 0.01f 
 // samplers.py:23-26: -log(-log(u + 1e-20) + 1e-20)
 __device__ __forceinline__ float sv_gumbel(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
 
+// Hardware-rate variants for the HBM-streaming likelihood kernel (v_exp_f32 / v_log_f32 / v_rcp_f32, each
+// ~1 ulp; the exponent scaling adds <= |x| * 2^-24 relative): the libm forms cost 10-30 VALU
+// instructions each and made that kernel instruction-bound at a third of the HBM rate.
+__device__ __forceinline__ float sv_fexp(float v) { return __expf(v); }
+__device__ __forceinline__ float sv_flog(float v) { return __logf(v); }
+__device__ __forceinline__ float sv_frcp(float v) { return __frcp_rn(v); }
+// log(1 + e), e >= 0, accurate for small e:  log(u) * e / (u - 1)  with u = fl(1 + e)
+__device__ __forceinline__ float sv_flog1p_pos(float e) {
+    const float u = 1.f + e, d = u - 1.f;
+    return d == 0.f ? e : sv_flog(u) * e * sv_frcp(d);
+}
+__device__ __forceinline__ float sv_softplus_fast(float v) { return v > 20.f ? v : sv_flog1p_pos(sv_fexp(v)); }
+__device__ __forceinline__ float sv_softplus_grad_from_out_fast(float sp) { return 1.f - sv_fexp(-sp); }
+__device__ __forceinline__ float sv_nll_normal_fast(float x, float mu, float sd, float& dmu, float& dsd) {
+    const float d = x - mu, inv = sv_frcp(sd), inv2 = inv * inv;
+    dmu = -d * inv2;
+    dsd = -d * d * inv2 * inv + inv;
+    return d * d * 0.5f * inv2 + sv_flog(sd) + 0.91893853320467274f;
+}
+__device__ __forceinline__ float sv_nll_bernoulli_fast(float x, float l, float& dl) {
+    const float e = sv_fexp(-fabsf(l));           // in (0, 1]
+    const float r = sv_frcp(1.f + e);
+    dl = (l >= 0.f ? r : e * r) - x;               // sigmoid(l) - x
+    return fmaxf(l, 0.f) - l * x + sv_flog1p_pos(e);
+}
+
 // Normal(mu, sd).log_prob, negated (base_missvae.py:130,277)
 __device__ __forceinline__ float sv_nll_normal(float x, float mu, float sd, float& dmu, float& dsd) {
     const float d = x - mu, inv = 1.f / sd, inv2 = inv * inv;

@@ -10,6 +10,9 @@
 // {nll_real, nll_pos, nll_bin, nll_cat, kl_z, kl_s}; a second, deterministic pass sums them over t.
 // The backward of the loss wrt the decoder outputs / z statistics / s logits is fused in the same
 // pass (one read of x, mask and the parameters serves both directions).
+#include <algorithm>
+#include <cstdlib>
+
 #include "cell_math.h"
 #include "common.h"
 
@@ -93,14 +96,177 @@ static int pow2_lanes(int n) {
     return ap;
 }
 
+// Streaming form.  Unit of work = (row, group of GA consecutive attributes, GA a multiple of 64 chosen so
+// that a group's spans fit a few KB): the attributes of a group occupy one contiguous span of the x
+// row, of the mask row and of the parameter row.  A wave pulls the 16-B aligned supersets of the three
+// spans into its private LDS slice with coalesced 16-B loads, each lane evaluates its attributes out of
+// LDS (descriptor table in LDS, shared by the workgroup), the parameter gradients overwrite the staged
+// parameters and leave as 16-B stores.  No workgroup barrier inside the loop: waves run independently,
+// 24 per CU, which is what hides the HBM latency.  Transcendentals use the hardware-rate forms of
+// cell_math.h.  Row sums: in-lane, then a fixed xor-shuffle tree (deterministic).
+struct NllStreamParams {
+    NllParams b;
+    int X, P, GA;
+    int xcap, pcap, mcap;  // LDS floats / floats / bytes per wave
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 6) void heter_nll_stream_kernel(NllStreamParams q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nll_smem[];
+    const NllParams& p = q.b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int D = p.D, GA = q.GA;
+    int4* at = reinterpret_cast<int4*>(nll_smem);  // {type, xoff, dim, poff}
+    unsigned char* slice = nll_smem + (size_t)D * 16 + (size_t)wid * (4 * (q.xcap + q.pcap) + q.mcap);
+    float* xs = reinterpret_cast<float*>(slice);
+    float* ps = xs + q.xcap;
+    unsigned char* ms = reinterpret_cast<unsigned char*>(ps + q.pcap);
+    for (int i = tid; i < D; i += 256) {
+        const AttrDesc ad = p.attrs[i];
+        at[i] = make_int4(ad.type, ad.xoff, ad.dim, ad.poff);
+    }
+    __syncthreads();
+
+    const int gw = blockIdx.x * 4 + wid, nw = gridDim.x * 4;
+    for (int row = gw; row < p.rows; row += nw) {
+        const float* xrow = p.x + (size_t)row * p.ldx;
+        const float* prow = p.P + (size_t)row * p.ldp;
+        const uint8_t* mrow = p.mask + (size_t)row * p.ldm;
+        float* drow = p.want_grad ? p.dP + (size_t)row * p.ldd : nullptr;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < D; g0 += GA) {
+            const int g1 = min(g0 + GA, D);
+            const int4 first = at[g0];
+            const int x0 = first.y, p0 = first.w;
+            const int x1 = g1 < D ? at[g1].y : q.X;
+            const int p1 = g1 < D ? at[g1].w : q.P;
+            // aligned supersets: element i of the span sits at LDS index delta + i
+            const float* xsrc = xrow + x0;
+            const float* psrc = prow + p0;
+            const uint8_t* msrc = mrow + x0;
+            const int dx = (int)((reinterpret_cast<uintptr_t>(xsrc) >> 2) & 3);
+            const int dp = (int)((reinterpret_cast<uintptr_t>(psrc) >> 2) & 3);
+            const int dm = (int)(reinterpret_cast<uintptr_t>(msrc) & 15);
+            const int np4 = (dp + (p1 - p0) + 3) >> 2, nx4 = (dx + (x1 - x0) + 3) >> 2, nm4 = (dm + (x1 - x0) + 15) >> 4;
+            {
+                const float4* s4 = reinterpret_cast<const float4*>(psrc - dp);
+                for (int i = lane; i < np4; i += 64) reinterpret_cast<float4*>(ps)[i] = s4[i];
+                const float4* t4 = reinterpret_cast<const float4*>(xsrc - dx);
+                for (int i = lane; i < nx4; i += 64) reinterpret_cast<float4*>(xs)[i] = t4[i];
+                const uint4* u4 = reinterpret_cast<const uint4*>(msrc - dm);
+                for (int i = lane; i < nm4; i += 64) reinterpret_cast<uint4*>(ms)[i] = u4[i];
+            }
+            wave_lds_sync();
+            for (int d = g0 + lane; d < g1; d += 64) {
+                const int4 ad = at[d];
+                const int type = ad.x, dim = ad.z;
+                const float* xr = xs + dx + (ad.y - x0);
+                float* pr = ps + dp + (ad.w - p0);
+                // base_missvae.py:271-274: one mask column; for cat the LAST one-hot column
+                const bool obs = ms[dm + (ad.y - x0) + dim - 1] == 0;
+                const float g = obs ? p.gs : 0.f;
+                float nll;
+                if (type <= 1) {  // real / pos: Normal(mu, std)
+                    const float mu = pr[0];
+                    const float sd = p.learn_std ? (FAST ? sv_softplus_fast(pr[1]) : sv_softplus(pr[1])) : SV_FIXED_STD;
+                    float dmu, dsd;
+                    nll = FAST ? sv_nll_normal_fast(xr[0], mu, sd, dmu, dsd) : sv_nll_normal(xr[0], mu, sd, dmu, dsd);
+                    if (p.want_grad) {
+                        pr[0] = dmu * g;
+                        if (p.learn_std) pr[1] = dsd * g * (FAST ? sv_softplus_grad_from_out_fast(sd) : sv_softplus_grad_from_out(sd));
+                    }
+                } else if (type == 2) {  // bin: Bernoulli(logits)
+                    float dl;
+                    nll = FAST ? sv_nll_bernoulli_fast(xr[0], pr[0], dl) : sv_nll_bernoulli(xr[0], pr[0], dl);
+                    if (p.want_grad) pr[0] = dl * g;
+                } else {  // cat: OneHotCategorical(logits = [0, theta_1..theta_{C-1}])
+                    float m = 0.f, xbest = xr[0], tsel = 0.f;
+                    int idx = 0;
+#pragma unroll 4
+                    for (int c = 1; c < dim; ++c) {
+                        const float th = pr[c - 1], xv = xr[c];
+                        m = fmaxf(m, th);
+                        if (xv > xbest) { xbest = xv; idx = c; tsel = th; }  // first max, as torch.max(-1)[1]
+                    }
+                    float se = FAST ? sv_fexp(-m) : expf(-m);
+#pragma unroll 4
+                    for (int c = 1; c < dim; ++c) {
+                        const float e = FAST ? sv_fexp(pr[c - 1] - m) : expf(pr[c - 1] - m);
+                        pr[c - 1] = e;  // the staged copy now holds exp(theta - m)
+                        se += e;
+                    }
+                    nll = m + (FAST ? sv_flog(se) : logf(se)) - tsel;
+                    if (p.want_grad) {
+                        const float inv = FAST ? sv_frcp(se) : 1.f / se;
+#pragma unroll 4
+                        for (int c = 1; c < dim; ++c) pr[c - 1] = (pr[c - 1] * inv - (c == idx ? 1.f : 0.f)) * g;
+                    }
+                }
+                const float v = obs ? nll : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += type == c ? v : 0.f;
+            }
+            wave_lds_sync();
+            if (p.want_grad) {
+                float* dsrc = drow + p0;
+                const int dd = (int)((reinterpret_cast<uintptr_t>(dsrc) >> 2) & 3);
+                if (dd == dp) {
+                    // same 16-B phase as the staged copy: whole float4 pieces inside the span, scalars at its edges
+                    float4* d4 = reinterpret_cast<float4*>(dsrc - dd);
+                    for (int i = lane; i < np4; i += 64) {
+                        const int lo = i * 4 - dp;  // span index of the piece's first element
+                        if (lo >= 0 && lo + 4 <= p1 - p0) d4[i] = reinterpret_cast<const float4*>(ps)[i];
+                        else
+                            for (int c = 0; c < 4; ++c)
+                                if (lo + c >= 0 && lo + c < p1 - p0) dsrc[lo + c] = ps[dp + lo + c];
+                    }
+                } else {
+                    for (int i = lane; i < p1 - p0; i += 64) dsrc[i] = ps[dp + i];
+                }
+            }
+            wave_lds_sync();  // the next staging overwrites this slice
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+        if (lane == 0) {
+            float* rl = p.rowloss + (size_t)row * 6;
+            rl[0] = acc[0]; rl[1] = acc[1]; rl[2] = acc[2]; rl[3] = acc[3];
+        }
+    }
+}
+
 int launch_heter_nll(const AttrDesc* attrs_dev, int D, int learn_std, const float* x, int ldx,
                      const uint8_t* mask, int ldm, const float* P, int ldp, float* dP, int ldd, int rows,
-                     float gs, float* rowloss, hipStream_t stream) {
+                     float gs, float* rowloss, int X, int Pw, int group, int xspan, int pspan, hipStream_t stream) {
     if (rows <= 0) return SHIVAE_OK;
     NllParams p;
     p.x = x; p.mask = mask; p.P = P; p.dP = dP; p.rowloss = rowloss; p.attrs = attrs_dev;
     p.ldx = ldx; p.ldm = ldm; p.ldp = ldp; p.ldd = ldd; p.rows = rows; p.D = D; p.learn_std = learn_std;
     p.ap = pow2_lanes(D); p.want_grad = dP != nullptr; p.gs = gs;
+    // group: attributes per staging step; xspan / pspan: widest x / parameter span of a group (plan_create)
+    NllStreamParams q;
+    q.b = p; q.X = X; q.P = Pw; q.GA = group;
+    q.xcap = round_up(xspan + 3, 4) + 4; q.pcap = round_up(pspan + 3, 4) + 4; q.mcap = round_up(xspan + 15, 16) + 16;
+    const size_t lds = (size_t)D * 16 + 4 * ((size_t)4 * (q.xcap + q.pcap) + q.mcap);
+    if (group > 0 && xspan > 0 && pspan > 0 && lds <= 64 * 1024) {
+        // 4 rounds of the workgroups that fit the chip (LDS; 6 waves per SIMD): enough rows per wave to
+        // amortise the descriptor table, short enough rounds that a mis-estimated residency costs a few
+        // per cent.  (One-wave workgroups reading descriptors from L2 measured 15 % slower.)
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, (160 * 1024) / lds));
+        const int grid = std::min(ceil_div(rows, 4), 256 * per_cu * 4);
+        static const bool exact = getenv("SHIVAE_NLL_EXACT") != nullptr;
+        if (exact) hipLaunchKernelGGL(heter_nll_stream_kernel<false>, dim3(grid), dim3(256), lds, stream, q);
+        else hipLaunchKernelGGL(heter_nll_stream_kernel<true>, dim3(grid), dim3(256), lds, stream, q);
+        SV_CHECK_HIP(hipGetLastError());
+        return SHIVAE_OK;
+    }
     const int rows_per_block = 4 * (64 / p.ap);
     const int blocks = std::min(ceil_div(rows, rows_per_block), 256 * 8);
     hipLaunchKernelGGL(heter_nll_kernel, dim3(blocks), dim3(256), 0, stream, p);
@@ -186,6 +352,93 @@ __global__ __launch_bounds__(256) void kl_kernel(KlParams p) {
     }
 }
 
+// 16-B form of kl_kernel: a lane owns 4 consecutive z (and 4 consecutive k) of a row, every load of a
+// row group is in flight before the first use, every store is a float4.  Needs 16-B aligned bases and
+// leading dimensions that are multiples of 4 with the rounded-up width inside the row.
+__global__ __launch_bounds__(256) void kl_vec_kernel(KlParams p) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int rpw = 64 / p.ap, sub = lane / p.ap, al = lane % p.ap;
+    const int Z4 = (p.Z + 3) >> 2, K4 = (p.K + 3) >> 2;
+    const float logq = logf(fminf(fmaxf(1.f / (float)p.K, SV_F32_EPS), 1.f - SV_F32_EPS));
+    for (int base = wave * rpw; base < p.rows; base += nwaves * rpw) {
+        const int row = base + sub;
+        const bool live = row < p.rows;
+        const size_t oz = (size_t)row * p.ldz, ok = (size_t)row * p.ldk;
+        float4 pk4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool hask = live && al < K4;
+        if (hask) pk4 = *reinterpret_cast<const float4*>(p.probs + ok + al * 4);
+        float klz = 0.f;
+        if (live)
+            for (int z4 = al; z4 < Z4; z4 += p.ap) {
+                const size_t o = oz + z4 * 4;
+                const float4 mq = *reinterpret_cast<const float4*>(p.mu + o), sq = *reinterpret_cast<const float4*>(p.sd + o);
+                const float4 mp = *reinterpret_cast<const float4*>(p.mup + o), sp = *reinterpret_cast<const float4*>(p.sdp + o);
+                const float mqv[4] = {mq.x, mq.y, mq.z, mq.w}, sqv[4] = {sq.x, sq.y, sq.z, sq.w};
+                const float mpv[4] = {mp.x, mp.y, mp.z, mp.w}, spv[4] = {sp.x, sp.y, sp.z, sp.w};
+                float ga[4], gb[4], gc[4], gd[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool v = z4 * 4 + c < p.Z;  // padded columns may hold anything
+                    float a, b, cc, d;
+                    const float kl = sv_kl_normal(mqv[c], sqv[c], mpv[c], spv[c], a, b, cc, d);
+                    klz += v ? kl : 0.f;
+                    ga[c] = v ? a * p.kz : 0.f;
+                    gb[c] = v ? b * p.kz : 0.f;
+                    gc[c] = v ? cc * p.kz : 0.f;
+                    gd[c] = v ? d * p.kz * sv_softplus_grad_from_out(spv[c]) : 0.f;
+                }
+                if (p.want_grad) {
+                    *reinterpret_cast<float4*>(p.dmu + o) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                    *reinterpret_cast<float4*>(p.dsd + o) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+                    *reinterpret_cast<float4*>(p.dmup + o) = make_float4(gc[0], gc[1], gc[2], gc[3]);
+                    *reinterpret_cast<float4*>(p.dsdp_pre + o) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+                }
+            }
+        // Categorical(probs): renormalise, clamp, KL against the uniform prior (base_missvae.py:332-343)
+        const float piv[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
+        bool kv[4];
+        float S = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { kv[c] = hask && al * 4 + c < p.K; S += kv[c] ? piv[c] : 0.f; }
+        for (int o = p.ap >> 1; o > 0; o >>= 1) S += __shfl_xor(S, o);
+        float kls = 0.f, pd = 0.f, dkl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float pk = kv[c] ? piv[c] / S : 0.f;
+            const bool inr = pk >= SV_F32_EPS && pk <= 1.f - SV_F32_EPS;
+            const float lp = logf(fminf(fmaxf(pk, SV_F32_EPS), 1.f - SV_F32_EPS));
+            dkl[c] = (kv[c] && pk != 0.f) ? (lp - logq) + (inr ? 1.f : 0.f) : 0.f;
+            if (kv[c] && pk != 0.f) { kls += pk * (lp - logq); pd += pk * dkl[c]; }
+        }
+        for (int o = p.ap >> 1; o > 0; o >>= 1) {
+            klz += __shfl_xor(klz, o);
+            kls += __shfl_xor(kls, o);
+            pd += __shfl_xor(pd, o);
+        }
+        if (kls != kls) kls = 0.f;
+        if (p.want_grad) {
+            // d/dprobs, then through probs = softmax(logits): dlg_j = pi_j (dpi_j - sum_k pi_k dpi_k)
+            float sdot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sdot += kv[c] ? piv[c] * (dkl[c] - pd) / S : 0.f;
+            for (int o = p.ap >> 1; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+            if (hask) {
+                float g[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) g[c] = kv[c] ? p.kz * piv[c] * ((dkl[c] - pd) / S - sdot) : 0.f;
+                *reinterpret_cast<float4*>(p.dlg + ok + al * 4) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        }
+        if (live && al == 0) {
+            p.rowloss[(size_t)row * 6 + 4] = klz;
+            p.rowloss[(size_t)row * 6 + 5] = kls;
+        }
+    }
+}
+
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 int launch_kl(const float* mu, const float* sd, const float* mup, const float* sdp, int ldz,
               const float* probs, int ldk, float* dmu, float* dsd, float* dmup, float* dsdp_pre, float* dlg,
               int rows, int Z, int K, float kz, float* rowloss, hipStream_t stream) {
@@ -193,11 +446,16 @@ int launch_kl(const float* mu, const float* sd, const float* mup, const float* s
     KlParams p;
     p.mu = mu; p.sd = sd; p.mup = mup; p.sdp = sdp; p.probs = probs;
     p.dmu = dmu; p.dsd = dsd; p.dmup = dmup; p.dsdp_pre = dsdp_pre; p.dlg = dlg; p.rowloss = rowloss;
-    p.ldz = ldz; p.ldk = ldk; p.rows = rows; p.Z = Z; p.K = K; p.ap = pow2_lanes(std::max(Z, K));
+    p.ldz = ldz; p.ldk = ldk; p.rows = rows; p.Z = Z; p.K = K;
     p.want_grad = dmu != nullptr; p.kz = kz;
+    const bool vec = ldz % 4 == 0 && ldk % 4 == 0 && round_up(Z, 4) <= ldz && round_up(K, 4) <= ldk && al16(mu) &&
+                     al16(sd) && al16(mup) && al16(sdp) && al16(probs) &&
+                     (!p.want_grad || (al16(dmu) && al16(dsd) && al16(dmup) && al16(dsdp_pre) && al16(dlg)));
+    p.ap = vec ? pow2_lanes(std::max(ceil_div(Z, 4), ceil_div(K, 4))) : pow2_lanes(std::max(Z, K));
     const int rows_per_block = 4 * (64 / p.ap);
     const int blocks = std::min(ceil_div(rows, rows_per_block), 256 * 8);
-    hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    if (vec) hipLaunchKernelGGL(kl_vec_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, stream, p);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
 }

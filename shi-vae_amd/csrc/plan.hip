@@ -71,6 +71,7 @@ struct shivae_plan {
     int64_t R;
     int Rc;
     int nbc;  // attributes with a hidden head layer (bin/cat)
+    int nll_group = 64, nll_xspan = 0, nll_pspan = 0;  // likelihood kernel: attributes per staging step, widest spans
     std::vector<AttrDesc> attrs;
     std::vector<int> bc_index;  // attr -> index among bin/cat, or -1
     std::vector<int> bc_attr;   // inverse
@@ -209,10 +210,6 @@ static void build_workspace(shivae_plan* p) {
     // chunk-local
     carve(p, "embc", Rc * p->E4, cur);
     carve(p, "dembc", Rc * p->E4, cur);
-    carve(p, "prc", Rc * Hp, cur);
-    carve(p, "dprc", Rc * Hp, cur);
-    carve(p, "dmupc", Rc * Zp, cur);
-    carve(p, "dsdp_prec", Rc * Zp, cur);
     carve(p, "a0", Rc * p->ldA0, cur);
     carve(p, "da0", Rc * p->ldA0, cur);
     for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Rc * p->ldA1, cur);
@@ -513,36 +510,65 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
     if (grad) SV_CHECK_HIP(hipMemsetAsync(d_emb, 0, (size_t)R * Ep * sizeof(float), s));
 
-    // 3. everything that only feeds the loss, in row chunks (prior shivae.py:124-127; decoder
-    //    decoders.py:109-176; losses base_missvae.py:233-343) with its backward right behind it
-    float *embc = p->wsf("embc"), *dembc = p->wsf("dembc"), *prc = p->wsf("prc"), *dprc = p->wsf("dprc");
-    float *mup = p->wsf("mup"), *sdp = p->wsf("sdp"), *dmupc = p->wsf("dmupc"), *dsdpc = p->wsf("dsdp_prec");
-    float *a0 = p->wsf("a0"), *a1 = p->wsf("a1"), *a2 = p->wsf("a2"), *pbuf = p->wsf("pbuf");
-    float *da0 = p->wsf("da0");
     const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
                 *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
     const float kz = beta * inv_batch;
+    // 3a. prior network + both KL terms + prior backward over ALL rows (blocks of <= 4M rows keep the GEMM
+    //     grids legal): shivae.py:124-127, base_missvae.py:287-343.  Scratch is borrowed from record
+    //     buffers that are only written after this point (by the backward scan / phi_x backward).
+    {
+        float *prc_all = p->wsf("d_phx_pre"), *dprc_all = p->wsf("d_p1_pre");
+        float *dmup_all = p->wsf("d_mu"), *dsdp_all = p->wsf("d_sd_pre");
+        float *mup = p->wsf("mup"), *sdp = p->wsf("sdp");
+        const int PB = 1 << 22;
+        for (int r0 = 0; r0 < R; r0 += PB) {
+            const int rb = std::min(PB, R - r0);
+            const float *emb_s = emb + (size_t)r0 * Ep + Hp, *emb_h = emb + (size_t)r0 * Ep + Hp + Kp;
+            float *prc = prc_all + (size_t)r0 * Hp, *dprc = dprc_all + (size_t)r0 * Hp;
+            float *mupc = mup + (size_t)r0 * Zp, *sdpc = sdp + (size_t)r0 * Zp;
+            float *dmupc = dmup_all + (size_t)r0 * Zp, *dsdpc = dsdp_all + (size_t)r0 * Zp;
+            // prior.0 takes cat[h, s] (shivae.py:124): columns [0,H) of its weight act on h, [H,H+K) on s
+            SV_TRY(gemm1(NT, rb, H, H, emb_h, Ep, Wp0, H + K, prc, Hp, nullptr, nullptr, 0, 0, s));
+            SV_TRY(gemm1(NT, rb, H, K, emb_s, Ep, Wp0 + H, H + K, prc, Hp, p->prm(g[SHIVAE_P_PRIOR0_B]), nullptr, 0,
+                         EPI_BIAS | EPI_ADDC | EPI_RELU, s));
+            SV_TRY(gemm1(NT, rb, Z, H, prc, Hp, Wpm, H, mupc, Zp, p->prm(g[SHIVAE_P_PRIORMEAN_B]), nullptr, 0, EPI_BIAS, s));
+            SV_TRY(gemm1(NT, rb, Z, H, prc, Hp, Wps, H, sdpc, Zp, p->prm(g[SHIVAE_P_PRIORSTD_B]), nullptr, 0,
+                         EPI_BIAS | EPI_SOFTPLUS, s));
+            // algorithmic bytes per row: mu, std (q and p) 16Z + probs 4K; the five gradients double it
+            prof_begin(PROF_KL, (double)rb * (16.0 * Z + 4.0 * K) * (grad ? 2.0 : 1.0), s);
+            SV_TRY(launch_kl(p->wsf("mu") + (size_t)r0 * Zp, p->wsf("sd") + (size_t)r0 * Zp, mupc, sdpc, Zp,
+                             p->wsf("probs") + (size_t)r0 * Kp, Kp, grad ? p->wsf("dmu_ext") + (size_t)r0 * Zp : nullptr,
+                             grad ? p->wsf("dsd_ext") + (size_t)r0 * Zp : nullptr, grad ? dmupc : nullptr,
+                             grad ? dsdpc : nullptr, grad ? p->wsf("dlg_kl") + (size_t)r0 * Kp : nullptr, rb, Z, K, kz,
+                             rowloss + (size_t)r0 * 6, s));
+            prof_end(s);
+            if (!grad) continue;
+            SV_TRY(gemm1(NN, rb, H, Z, dmupc, Zp, Wpm, H, dprc, Hp, nullptr, nullptr, 0, 0, s));
+            SV_TRY(gemm1(NN, rb, H, Z, dsdpc, Zp, Wps, H, dprc, Hp, nullptr, prc, Hp, EPI_ADDC | EPI_MASK, s));
+            SV_TRY(gemm1(TN, Z, H, rb, dmupc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(gemm1(TN, Z, H, rb, dsdpc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(colsum1(rb, Z, Zp, dmupc, p->grd(g[SHIVAE_P_PRIORMEAN_B]), s));
+            SV_TRY(colsum1(rb, Z, Zp, dsdpc, p->grd(g[SHIVAE_P_PRIORSTD_B]), s));
+            float* gWp0 = p->grd(g[SHIVAE_P_PRIOR0_W]);
+            SV_TRY(gemm1(TN, H, H, rb, dprc, Hp, emb_h, Ep, gWp0, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(gemm1(TN, H, K, rb, dprc, Hp, emb_s, Ep, gWp0 + H, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
+            SV_TRY(colsum1(rb, H, Hp, dprc, p->grd(g[SHIVAE_P_PRIOR0_B]), s));
+            // into the (zeroed) d_emb records; the decoder chunks add their part below
+            float* de = d_emb + (size_t)r0 * Ep;
+            SV_TRY(gemm1(NN, rb, H, H, dprc, Hp, Wp0, H + K, de + Hp + Kp, Ep, nullptr, nullptr, 0, 0, s));
+            SV_TRY(gemm1(NN, rb, K, H, dprc, Hp, Wp0 + H, H + K, de + Hp, Ep, nullptr, nullptr, 0, 0, s));
+        }
+    }
+
+    // 3b. the decoder and its likelihood, in row chunks (decoders.py:109-176, base_missvae.py:233-285),
+    //     each chunk's backward right behind its forward
+    float *embc = p->wsf("embc"), *dembc = p->wsf("dembc");
+    float *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
+    float *da0 = p->wsf("da0");
     const int ldA0 = p->ldA0, ldA1 = p->ldA1, ldHH = p->ldHH;
     for (int r0 = 0; r0 < R; r0 += p->Rc) {
         const int rc = std::min(p->Rc, R - r0);
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
-        const float *emb_z = embc, *emb_s = embc + H, *emb_h = embc + H + K;
-        (void)emb_z;
-        // prior.0 takes cat[h, s] (shivae.py:124): columns [0,H) of its weight act on h, [H,H+K) on s
-        SV_TRY(gemm1(NT, rc, H, H, emb_h, E4, Wp0, H + K, prc, Hp, nullptr, nullptr, 0, 0, s));
-        SV_TRY(gemm1(NT, rc, H, K, emb_s, E4, Wp0 + H, H + K, prc, Hp, p->prm(g[SHIVAE_P_PRIOR0_B]), nullptr, 0,
-                     EPI_BIAS | EPI_ADDC | EPI_RELU, s));
-        float *mupc = mup + (size_t)r0 * Zp, *sdpc = sdp + (size_t)r0 * Zp;
-        SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wpm, H, mupc, Zp, p->prm(g[SHIVAE_P_PRIORMEAN_B]), nullptr, 0, EPI_BIAS, s));
-        SV_TRY(gemm1(NT, rc, Z, H, prc, Hp, Wps, H, sdpc, Zp, p->prm(g[SHIVAE_P_PRIORSTD_B]), nullptr, 0,
-                     EPI_BIAS | EPI_SOFTPLUS, s));
-        prof_begin(PROF_KL, (double)rc * (16.0 * Z + 4.0 * K) * (grad ? 2.0 : 1.0), s);
-        SV_TRY(launch_kl(p->wsf("mu") + (size_t)r0 * Zp, p->wsf("sd") + (size_t)r0 * Zp, mupc, sdpc, Zp,
-                         p->wsf("probs") + (size_t)r0 * Kp, Kp, grad ? p->wsf("dmu_ext") + (size_t)r0 * Zp : nullptr,
-                         grad ? p->wsf("dsd_ext") + (size_t)r0 * Zp : nullptr, grad ? dmupc : nullptr,
-                         grad ? dsdpc : nullptr, grad ? p->wsf("dlg_kl") + (size_t)r0 * Kp : nullptr, rc, Z, K, kz,
-                         rowloss + (size_t)r0 * 6, s));
-        prof_end(s);
         // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
         SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
                      nullptr, 0, EPI_BIAS | EPI_RELU, s));
@@ -558,7 +584,7 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         // algorithmic bytes per row: x (4X) + mask (X) + parameters (4P), + the gradient write (4P) in training
         prof_begin(PROF_NLL, (double)rc * (5.0 * X + 4.0 * P * (grad ? 2.0 : 1.0)), s);
         SV_TRY(launch_heter_nll(p->attrs_dev, D, p->learn_std, x + (size_t)r0 * X, X, mask + (size_t)r0 * X, X, pbuf, P,
-                                grad ? pbuf : nullptr, P, rc, inv_batch, rowloss + (size_t)r0 * 6, s));
+                                grad ? pbuf : nullptr, P, rc, inv_batch, rowloss + (size_t)r0 * 6, X, P, p->nll_group, p->nll_xspan, p->nll_pspan, s));
         prof_end(s);
         if (!grad) continue;
 
@@ -585,19 +611,6 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         SV_TRY(colsum1(rc, D * 2 * H, ldA0, da0, p->grd(g[SHIVAE_P_DEC0_B]), s));
         SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
 
-        // ---- prior backward ----
-        SV_TRY(gemm1(NN, rc, H, Z, dmupc, Zp, Wpm, H, dprc, Hp, nullptr, nullptr, 0, 0, s));
-        SV_TRY(gemm1(NN, rc, H, Z, dsdpc, Zp, Wps, H, dprc, Hp, nullptr, prc, Hp, EPI_ADDC | EPI_MASK, s));
-        SV_TRY(gemm1(TN, Z, H, rc, dmupc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(gemm1(TN, Z, H, rc, dsdpc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(rc, Z, Zp, dmupc, p->grd(g[SHIVAE_P_PRIORMEAN_B]), s));
-        SV_TRY(colsum1(rc, Z, Zp, dsdpc, p->grd(g[SHIVAE_P_PRIORSTD_B]), s));
-        float* gWp0 = p->grd(g[SHIVAE_P_PRIOR0_W]);
-        SV_TRY(gemm1(TN, H, H, rc, dprc, Hp, emb_h, E4, gWp0, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(gemm1(TN, H, K, rc, dprc, Hp, emb_s, E4, gWp0 + H, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(rc, H, Hp, dprc, p->grd(g[SHIVAE_P_PRIOR0_B]), s));
-        SV_TRY(gemm1(NN, rc, H, H, dprc, Hp, Wp0, H + K, dembc + H + K, E4, nullptr, nullptr, 0, EPI_ADDC, s));
-        SV_TRY(gemm1(NN, rc, K, H, dprc, Hp, Wp0 + H, H + K, dembc + H, E4, nullptr, nullptr, 0, EPI_ADDC, s));
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
     }
 
@@ -698,6 +711,20 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         if (bc) { p->bc_attr.push_back(d); p->nbc++; }
     }
     p->X = xoff; p->P = poff; p->E = 2 * p->H + p->K;
+    // likelihood kernel: largest group of attributes (multiple of 64) whose x + mask + parameter spans stay
+    // within ~6 KB of LDS per wave (keeps 24-32 waves per CU resident)
+    for (int ga = 64;; ga *= 2) {
+        int xs = 0, ps = 0;
+        for (int d0 = 0; d0 < p->D; d0 += ga) {
+            const int d1 = std::min(d0 + ga, p->D);
+            const int xe = d1 < p->D ? p->attrs[d1].xoff : p->X, pe = d1 < p->D ? p->attrs[d1].poff : p->P;
+            xs = std::max(xs, xe - p->attrs[d0].xoff);
+            ps = std::max(ps, pe - p->attrs[d0].poff);
+        }
+        if (ga > 64 && 5 * xs + 4 * ps > 6144) break;
+        p->nll_group = ga; p->nll_xspan = xs; p->nll_pspan = ps;
+        if (ga >= p->D) break;
+    }
     p->Hp = round_up(p->H, 16); p->Zp = round_up(p->Z, 16); p->Kp = round_up(p->K, 16);
     p->Ep = 2 * p->Hp + p->Kp; p->E4 = round_up(p->E, 4); p->Z4 = round_up(p->Z, 4);
     if (p->Hp > 512) {
@@ -842,7 +869,7 @@ int shivae_heter_nll(shivae_plan* p, const float* x, const uint8_t* mask, const 
         SV_TRY(upload(p, p->attrs, &p->attrs_dev));
     }
     return launch_heter_nll(p->attrs_dev, p->D, p->learn_std, x, p->X, mask, p->X, params, ldp, dparams, ldp, rows, gs,
-                            rowloss, static_cast<hipStream_t>(stream));
+                            rowloss, p->X, p->P, p->nll_group, p->nll_xspan, p->nll_pspan, static_cast<hipStream_t>(stream));
 }
 
 int shivae_kl_terms(const float* mu_q, const float* std_q, const float* mu_p, const float* std_p, int ldz,
