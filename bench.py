@@ -117,6 +117,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:  # a full-size step takes about a minute: keep stderr alive for watchdogs (no GPU work here)
+        import threading
+        t_start = time.perf_counter()
+        def heartbeat():
+            while True:
+                time.sleep(30)
+                print("[bench] running, %.0f s elapsed" % (time.perf_counter() - t_start), file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
     for _ in range(a.warmup):
         loss = step()
     fence()

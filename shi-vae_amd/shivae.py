@@ -82,6 +82,7 @@ class ShiVAE(nn.Module):
         self.chunk_rows = int(os.environ.get("SHIVAE_CHUNK_ROWS", "0"))
         self._pending_noise = None
         self._plans = {}
+        self._chunk_done = set()
         self._active = None
         self._workspace = None
         self._last = None
@@ -229,12 +230,32 @@ class ShiVAE(nn.Module):
                                       "is no CPU fallback" % self._flat.device)
         N.lib()
 
-    def _make_plan(self, T, B):
+    def _make_plan(self, T, B, chunk_rows=None):
         key = (T, B)
+        if chunk_rows is not None:
+            self._plans.pop(key, None)
         if key not in self._plans:
             self._plans[key] = N.Plan(T, B, self.h_dim, self.z_dim, self.s_dim, self._attr_types, self._attr_ncls,
-                                      self.learn_std, self.chunk_rows)
+                                      self.learn_std, self.chunk_rows if chunk_rows is None else chunk_rows)
         return self._plans[key]
+
+    def _grow_chunk(self, T, B):
+        """Give the memory a micro-batch leaves unused to the decoder row chunk (fewer, larger launches).
+        Workspace is linear in the chunk rows, so two plans give the slope."""
+        if self.chunk_rows or (T, B) in self._chunk_done:
+            return
+        self._chunk_done.add((T, B))
+        budget = self._budget()
+        p0 = self._make_plan(T, B)
+        rc0, ws0 = p0.chunk_rows, p0.workspace_bytes
+        if rc0 >= T * B or ws0 >= budget:
+            return
+        rc1 = min(T * B, 2 * rc0)
+        ws1 = self._make_plan(T, B, chunk_rows=rc1).workspace_bytes
+        per_row = max(1.0, (ws1 - ws0) / float(rc1 - rc0))
+        rc = int(min(T * B, rc0 + 0.9 * (budget - ws0) / per_row)) // 128 * 128
+        self._make_plan(T, B, chunk_rows=max(rc, rc0))
+        self._active = None
 
     def _budget(self):
         if self.workspace_limit_bytes:
@@ -309,6 +330,7 @@ class ShiVAE(nn.Module):
         if bm < B:  # equal-sized micro-batches (one plan, no re-binding), multiples of the 16-sequence scan tile
             nmb = -(-B // bm)
             bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
+        self._grow_chunk(T, min(bm, B))
         outs = {w: [] for w in (collect or [])}
         persum = []
         L = N.lib()
