@@ -52,6 +52,7 @@ struct GemmGroup {
     float* C;
     const float* bias;  // [N] or null
     const float* aux;   // [M,N] activation whose sign gates the output (ReLU backward) or null
+    float* csum;        // [N] column sums of the stored C are ADDED here (EPI_COLSUM: bias gradient) or null
 };
 
 enum GemmLayout {
@@ -70,6 +71,7 @@ enum GemmEpi {
     EPI_ADDC = 8,      // + C_old (before the activation)
     EPI_MASK = 16,     // * (aux[m,n] > 0)   (after everything else)
     EPI_ATOMIC = 32,   // atomicAdd into C (split-K / cross-launch accumulation); excludes the others
+    EPI_COLSUM = 64,   // csum[n] += sum_m C[m,n] of the values stored (fused bias gradient of an input-gradient GEMM)
 };
 
 struct GemmDesc {

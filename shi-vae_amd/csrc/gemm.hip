@@ -197,6 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
             static_assert(NT % (BN / 4) == 0, "a thread keeps its columns across pieces");
             const int c4 = tid % (BN / 4), col = n0 + c4 * 4;
             const bool colok = col < p.N;
+            float cs4[4] = {0.f, 0.f, 0.f, 0.f};  // EPI_COLSUM: this thread's share of the column sums
             float bias4[4] = {0.f, 0.f, 0.f, 0.f};
             if ((epi & EPI_BIAS) && colok) {
 #pragma unroll
@@ -270,9 +271,24 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                             e[2] = a4.z > 0.f ? e[2] : 0.f; e[3] = a4.w > 0.f ? e[3] : 0.f;
                         }
                         *reinterpret_cast<float4*>(cp) = make_float4(e[0], e[1], e[2], e[3]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) cs4[c] += e[c];
                     }
                 }
                 if (pi + 1 < BANDS / G) __syncthreads();
+            }
+            if (epi & EPI_COLSUM) {
+                // the NT / (BN/4) threads that share 4 columns meet in LDS; one atomic per column and tile
+                static_assert(NT * 4 <= (DB ? 2 : 1) * STAGE, "column-sum staging fits the tile's LDS");
+                __syncthreads();
+                *reinterpret_cast<float4*>(lds + (tid / (BN / 4)) * BN + c4 * 4) = make_float4(cs4[0], cs4[1], cs4[2], cs4[3]);
+                __syncthreads();
+                if (tid < BN && n0 + tid < p.N) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NT / (BN / 4); ++k) t += lds[k * BN + tid];
+                    atomicAdd(g.csum + n0 + tid, t);
+                }
             }
             return;
         }
@@ -285,6 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
             const int col = n0 + (wn * TN + y) * 32 + li;
             if (col >= p.N) continue;
             const float bias = (epi & EPI_BIAS) ? g.bias[col] : 0.f;
+            float cs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -301,7 +318,9 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                 if (epi & EPI_SOFTPLUS) v = softplus_f(v);
                 if (epi & EPI_MASK) v = g.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
                 *cp = v;
+                cs += v;
             }
+            if (epi & EPI_COLSUM) atomicAdd(g.csum + col, cs);
         }
 }
 
@@ -352,6 +371,7 @@ int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, con
     SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "gemm: %d groups need a device group table", ngroups);
     SV_REQUIRE(d.splitk == 1 || (d.epi == EPI_ATOMIC), "gemm: split-K needs the atomic epilogue");
     SV_REQUIRE(!(d.epi & EPI_ATOMIC) || d.epi == EPI_ATOMIC, "gemm: atomic epilogue excludes the others");
+    SV_REQUIRE(!(d.epi & EPI_COLSUM) || groups_dev != nullptr || g0.csum != nullptr, "gemm: EPI_COLSUM needs csum");
     GemmParams p;
     p.M = d.M; p.N = d.N; p.K = d.K;
     p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux;

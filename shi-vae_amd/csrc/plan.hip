@@ -95,7 +95,6 @@ struct shivae_plan {
     std::vector<void*> owned;  // device allocations to free
     // grouped-GEMM tables
     GroupTable f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
-    ColTable c_l1, c_l2, c_h0;
     std::map<int, GroupTable> f_out, b_out_w, b_out_d;  // keyed by nout
     std::map<int, ColTable> c_out;
 
@@ -323,7 +322,6 @@ static int build_tables(shivae_plan* p) {
     auto PA = [&](int id, int d) { return p->params + p->per_attr[id][d].off; };
     auto GA = [&](int id, int d) { return p->grads + p->per_attr[id][d].off; };
     std::vector<GemmGroup> fl1, fl2, fh0, wl1, dl1, wl2, dl2, wh0, dh0;
-    std::vector<ColsumGroup> cl1, cl2, ch0;
     std::map<int, std::vector<GemmGroup>> fo, wo, dO;
     std::map<int, std::vector<ColsumGroup>> co;
     for (int d = 0; d < D; ++d) {
@@ -334,11 +332,10 @@ static int build_tables(shivae_plan* p) {
         fl1.push_back({a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr});
         fl2.push_back({a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr});
         wl2.push_back({da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr});
-        cl2.push_back({da2d, GA(SHIVAE_P_DEC4_B, d)});
-        dl2.push_back({da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d});
+        dl2.push_back({da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d, GA(SHIVAE_P_DEC2_B, d)});
         wl1.push_back({da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr});
-        cl1.push_back({da1d, GA(SHIVAE_P_DEC2_B, d)});
-        dl1.push_back({da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d});
+        dl1.push_back({da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d,
+                       p->grads + p->glob[SHIVAE_P_DEC0_B].off + (size_t)d * 2 * H});
         // heads (decoders.py:69-102)
         float* wout = p->params + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
         float* bout = p->params + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
@@ -346,15 +343,14 @@ static int build_tables(shivae_plan* p) {
         float* gbout = p->grads + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
         float* pd = pb + a.poff;
         const float* hin = a2d;
-        float *dhin = da2d, *hmask = a2d;
+        float *dhin = da2d, *hmask = a2d, *dhbias = GA(SHIVAE_P_DEC4_B, d);
         if (p->bc_index[d] >= 0) {
             const int jx = p->bc_index[d];
             float *hhj = hh + (size_t)jx * H, *dhhj = dhh + (size_t)jx * H;
             fh0.push_back({a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr});
             wh0.push_back({dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr});
-            ch0.push_back({dhhj, GA(SHIVAE_P_HEAD0_B, d)});
-            dh0.push_back({dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d});
-            hin = hhj; dhin = dhhj; hmask = hhj;
+            dh0.push_back({dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d, GA(SHIVAE_P_DEC4_B, d)});
+            hin = hhj; dhin = dhhj; hmask = hhj; dhbias = GA(SHIVAE_P_HEAD0_B, d);
         }
         // tables are keyed by +nout (input = hh, bin/cat) or -nout (input = a2, real/pos): the two
         // inputs have different leading dimensions, and a grouped launch shares them
@@ -362,13 +358,12 @@ static int build_tables(shivae_plan* p) {
         fo[key].push_back({hin, wout, pd, bout, nullptr});
         wo[key].push_back({pd, hin, gwout, nullptr, nullptr});
         co[key].push_back({pd, gbout});
-        dO[key].push_back({pd, wout, dhin, nullptr, hmask});
+        dO[key].push_back({pd, wout, dhin, nullptr, hmask, dhbias});
     }
     SV_TRY(make_table(p, fl1, p->f_l1)); SV_TRY(make_table(p, fl2, p->f_l2)); SV_TRY(make_table(p, fh0, p->f_h0));
     SV_TRY(make_table(p, wl1, p->b_l1_w)); SV_TRY(make_table(p, dl1, p->b_l1_d));
     SV_TRY(make_table(p, wl2, p->b_l2_w)); SV_TRY(make_table(p, dl2, p->b_l2_d));
     SV_TRY(make_table(p, wh0, p->b_h0_w)); SV_TRY(make_table(p, dh0, p->b_h0_d));
-    SV_TRY(make_ctable(p, cl1, p->c_l1)); SV_TRY(make_ctable(p, cl2, p->c_l2)); SV_TRY(make_ctable(p, ch0, p->c_h0));
     for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first]));
     for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first]));
     for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first]));
@@ -593,22 +588,19 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
             const int key = kv.first, nout = key < 0 ? -key : key, ldin = key < 0 ? ldA1 : ldHH;
             SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s));
             SV_TRY(colsumg(rc, nout, P, p->c_out[key], s));
-            // d(head input) = dP * Wout, gated by the head input's ReLU
-            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK, p->b_out_d[key], s));
+            // d(head input) = dP * Wout, gated by the head input's ReLU; its column sums are the bias gradient
+            // of the layer that produced the head input (EPI_COLSUM, here and in the trunk below)
+            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s));
         }
         SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s));
-        SV_TRY(colsumg(rc, H, ldHH, p->c_h0, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK, p->b_h0_d, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s));
         SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s));
-        SV_TRY(colsumg(rc, H, ldA1, p->c_l2, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK, p->b_l2_d, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s));
         SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s));
-        SV_TRY(colsumg(rc, H, ldA1, p->c_l1, s));
-        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK, p->b_l1_d, s));
+        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s));
         // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
         SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                      EPI_ATOMIC, s));
-        SV_TRY(colsum1(rc, D * 2 * H, ldA0, da0, p->grd(g[SHIVAE_P_DEC0_B]), s));
         SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
 
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
