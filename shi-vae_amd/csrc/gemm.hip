@@ -86,9 +86,33 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int s, in
 
 struct GemmParams {
     int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB, vecC;
+    // tile -> workgroup map (see tile_coords): tile counts, super-tile shape (SX*SY*SZ = 64), super-tile counts
+    int ntx, nty, ntz, SX, SY, SZ, cx, cy, nsuper;
     const GemmGroup* groups;
     GemmGroup g0;
 };
+
+// XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id and each XCD has its own
+// 4 MiB L2, so with the plain (x fastest) order the column tiles that share an A tile sit on different
+// XCDs and every operand tile is fetched over the fabric once per consumer (measured with FETCH_SIZE: 3x
+// the algorithmic read bytes).  Here the tile grid is cut into super-tiles of 64 tiles (SX x SY x SZ,
+// neighbours in n, m and group/split); super-tile s belongs to XCD s % 8, and the 64 workgroups that
+// XCD receives back to back are exactly that super-tile, so shared operand tiles meet in one L2.
+__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& bx, int& by, int& bz) {
+    const int lin = blockIdx.x;
+    if (p.nsuper == 0) {  // plain order
+        bx = lin % p.ntx; by = (lin / p.ntx) % p.nty; bz = lin / (p.ntx * p.nty);
+        return true;
+    }
+    const int xcd = lin & 7, k = lin >> 3;
+    const int s = (k >> 6) * 8 + xcd, within = k & 63;
+    if (s >= p.nsuper) return false;
+    const int sx = s % p.cx, sy = (s / p.cx) % p.cy, sz = s / (p.cx * p.cy);
+    bx = sx * p.SX + within % p.SX;
+    by = sy * p.SY + (within / p.SX) % p.SY;
+    bz = sz * p.SZ + within / (p.SX * p.SY);
+    return bx < p.ntx && by < p.nty && bz < p.ntz;
+}
 
 template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int WPE, bool DB>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
@@ -104,9 +128,11 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int gidx = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+    int bx, by, bz;
+    if (!tile_coords(p, bx, by, bz)) return;  // padding of the last super-tiles (uniform per workgroup)
+    const int gidx = bz / p.splitk, ks = bz % p.splitk;
     const GemmGroup g = p.groups ? p.groups[gidx] : p.g0;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = ks * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -333,12 +359,28 @@ static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     constexpr int tile = (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
                        : (BM == 64 && BN == 256) ? 3 : (BM == 128 && BN == 128) ? 4 : 5;
     (void)tile;
-    dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), ngroups * p.splitk);
-    SV_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm grid too large (M=%d groups=%d splitk=%d)", p.M,
-               ngroups, p.splitk);
+    GemmParams q = p;
+    q.ntx = ceil_div(p.N, BN); q.nty = ceil_div(p.M, BM); q.ntz = ngroups * p.splitk;
+    const long long tiles = (long long)q.ntx * q.nty * q.ntz;
+    static const bool swizzle = [] { const char* f = getenv("SHIVAE_GEMM_SWIZZLE"); return !f || atoi(f) != 0; }();
+    long long nblocks = tiles;
+    q.nsuper = 0;
+    if (swizzle && tiles >= 512) {
+        auto pow2_le = [](int v, int cap) { int r = 1; while (r * 2 <= v && r * 2 <= cap) r *= 2; return r; };
+        q.SX = pow2_le(q.ntx, 8);
+        q.SY = pow2_le(q.nty, 64 / q.SX);
+        q.SZ = 64 / (q.SX * q.SY);
+        q.cx = ceil_div(q.ntx, q.SX); q.cy = ceil_div(q.nty, q.SY);
+        const long long ns = (long long)q.cx * q.cy * ceil_div(q.ntz, q.SZ);
+        SV_REQUIRE(ns < (1ll << 24), "gemm: too many tiles");
+        q.nsuper = (int)ns;
+        nblocks = (ns + 7) / 8 * 8 * 64;
+    }
+    SV_REQUIRE(nblocks < (1ll << 31), "gemm grid too large (M=%d groups=%d splitk=%d)", p.M, ngroups, p.splitk);
+    dim3 grid((unsigned)nblocks);
     prof_shape(p.M, p.N, p.K, ngroups);
     prof_begin(layout * 6 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
-    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN, MINB, DB>), grid, dim3(WM * WN * 64), 0, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN, MINB, DB>), grid, dim3(WM * WN * 64), 0, stream, q);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
