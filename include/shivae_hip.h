@@ -180,6 +180,32 @@ int shivae_clip_adam(float* params_dev, const float* grads_dev, float* exp_avg_d
                      int64_t n, const float* sqnorm_dev, float clip, float lr, float beta1, float beta2,
                      float eps, int step, shivae_stream stream);
 
+/* ---- pre/post pass either side of the step ---------------------------- */
+/* One attribute of a fitted HeterogeneousScaler (lib/scalers.py:27-58): type, first one-hot/x column
+ * (utils.get_idx_transform, lib/utils.py:291-315), x columns (1, or nclass for cat), raw column
+ * ('index'), and the fitted moments (StandardScaler / PositiveScaler .mean/.std, scalers.py:223-289;
+ * unused for bin/cat). */
+typedef struct {
+    int type, xoff, dim, index;
+    double mean, std;
+} shivae_scale_attr;
+enum { SHIVAE_SCALE_TRANSPOSE = 1, SHIVAE_SCALE_ZERO_FILL = 2, SHIVAE_SCALE_F64 = 4 };
+/* HeterogeneousScaler.transform (scalers.py:85-131) fused with Trainer.preprocess_batch
+ * (models/train.py:333-362) and utils.zero_fill (lib/utils.py:89-100): raw data[n][t][n_attr], f32 or
+ * (flag F64, what the reference's numpy datasets hold) f64, scaled in f64 and stored as f32 like the
+ * reference (NaN allowed) + mask[n][t][n_attr] u8 (NULL: mask = isnan(data)) -> x[t][n][x_dim] (TRANSPOSE) or
+ * x[n][t][x_dim], mask replicated over one-hot columns; ZERO_FILL writes 0 at masked entries.
+ * col2attr_dev[x_dim]: attribute of every x column.  Categories are the integers 0..nclass-1. */
+int shivae_scale_transform(const void* data_dev, const uint8_t* mask_dev, int n, int t, int n_attr, int x_dim,
+                           const shivae_scale_attr* attrs_dev, const int* col2attr_dev, float* x_dev,
+                           uint8_t* mask_out_dev, int flags, shivae_stream stream);
+/* HeterogeneousScaler.inverse_transform (scalers.py:133-183): x (layout as above) -> data[n][t][n_attr]
+ * (f32, or f64 with flag F64);
+ * mask_dev (x layout, may be NULL) -> mask_out_dev[n][t][n_attr] (may be NULL). */
+int shivae_scale_inverse(const float* x_dev, const uint8_t* mask_dev, int n, int t, int n_attr, int x_dim,
+                         const shivae_scale_attr* attrs_dev, void* data_dev, uint8_t* mask_out_dev, int flags,
+                         shivae_stream stream);
+
 /* ---- measurement support (no counterpart in the reference) ---------------------------------- */
 /* Bracket every kernel launch of the following calls with HIP events on the launch stream.
  * shivae_profile_stop synchronises the device and writes up to max_entries records of 4 doubles

@@ -20,6 +20,7 @@ P = {n: i for i, n in enumerate(_P_NAMES)}
 _O_NAMES = ["Z", "Z_MEAN", "Z_STD", "ZP_MEAN", "ZP_STD", "S", "S_PROBS", "DEC_PARAMS", "ROWLOSS", "H_PREV", "PHI_Z"]
 O = {n: i for i, n in enumerate(_O_NAMES)}
 STEP_FORWARD_ONLY, STEP_KEEP_PARAMS = 1, 2
+SCALE_TRANSPOSE, SCALE_ZERO_FILL, SCALE_F64 = 1, 2, 4
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 16, 32
 
@@ -29,7 +30,8 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_
            "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
-           "shivae_clip_adam", "shivae_profile_start", "shivae_profile_stop"]
+           "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start",
+           "shivae_profile_stop"]
 
 
 class Config(C.Structure):
@@ -81,6 +83,8 @@ def lib():
     L.shivae_zero.argtypes = [vp, i64, vp]
     L.shivae_sqnorm.argtypes = [vp, i64, vp, vp, vp]
     L.shivae_clip_adam.argtypes = [vp, vp, vp, vp, i64, vp, cf, cf, cf, cf, cf, ci, vp]
+    L.shivae_scale_transform.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp]
+    L.shivae_scale_inverse.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     L.shivae_profile_start.argtypes = []
     L.shivae_profile_stop.argtypes = [C.POINTER(C.c_double), ci]
     _lib = L

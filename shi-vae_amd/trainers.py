@@ -134,6 +134,9 @@ class Trainer:
 
     def preprocess_batch(self, data, mask):
         """train.py:333-362: scale, B,T,D -> T,B,D, float32 / bool tensors on the model's device."""
+        if self.scaler is not None and hasattr(self.scaler, "transform_to_device"):
+            # one HIP pass: scale + one-hot + mask replication + B,T,D -> T,B,X + zero fill (csrc/prep.hip)
+            return self.scaler.transform_to_device(data, mask, transpose=True, zero_fill=True)
         if self.scaler is not None:
             data, mask = self.scaler.transform(data, mask)
         data = torch.as_tensor(np.asarray(data).transpose(1, 0, 2)).float().to(self.model.flat_params.device)
