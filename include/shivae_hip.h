@@ -148,6 +148,11 @@ int shivae_get_persum(shivae_plan* plan, float* dst_dev, shivae_stream stream);
 int shivae_heter_nll(shivae_plan* plan, const float* x_dev, const uint8_t* mask_dev, const float* params_dev,
                      int ldp, float* dparams_dev, int rows, float grad_scale, float* rowloss_dev,
                      shivae_stream stream);
+/* base_missvae.py:378-404 generate_heter_samples: xhat[rows][x_dim] = per attribute the mean of n_samples
+ * draws from its likelihood (real/pos Normal, bin Bernoulli, cat one-hot), rounded for bin/cat.  Draws come
+ * from a counter-based generator keyed by (seed, row, attribute, sample). */
+int shivae_mc_impute(shivae_plan* plan, const float* params_dev, int ldp, int rows, int n_samples, uint64_t seed,
+                     float* xhat_dev, shivae_stream stream);
 /* base_missvae.py:287-343 kl_q_z + kl_q_s forward (rowloss columns 4,5), fused with their gradients
  * scaled by kl_scale (= beta*grad_scale): d/dmu_q, d/dstd_q, d/dmu_p, d/d(pre-softplus std_p) and
  * d/d(s logits) through s_probs = softmax(logits).  Gradient pointers may all be NULL. */

@@ -112,6 +112,8 @@ int launch_heter_nll(const AttrDesc* attrs_dev, int D, int learn_std, const floa
                      const uint8_t* mask, int ldm, const float* P, int ldp, float* dP, int ldd, int rows,
                      float gs, float* rowloss, int X, int Pw, int group, int xspan, int pspan, hipStream_t stream);
 // X, Pw: widths of x / P rows; group: attributes per staging step (multiple of 64); xspan, pspan: widest x / P span of a group
+int launch_mc_impute(const AttrDesc* attrs_dev, int D, int learn_std, const float* P, int ldp, long long rows,
+                     int n_samples, uint64_t seed, float* xhat, int ldx, hipStream_t stream);
 int launch_kl(const float* mu, const float* sd, const float* mup, const float* sdp, int ldz,
               const float* probs, int ldk, float* dmu, float* dsd, float* dmup, float* dsdp_pre, float* dlg,
               int rows, int Z, int K, float kz, float* rowloss, hipStream_t stream);

@@ -510,6 +510,86 @@ int launch_loss_reduce(const float* rowloss, float* persum, int T, int B, float 
     return SHIVAE_OK;
 }
 
+// ---------------------------------------------------------------- Monte-Carlo imputation samples
+// base_missvae.py:378-404 generate_heter_samples: per attribute the mean of n_samples draws from its
+// likelihood (rounded for bin / cat), written in the x layout.  One thread per (row, attribute); draws come
+// from a counter-based generator keyed by (seed, row, attribute, sample) so the result does not depend on
+// the launch geometry.  The reference draws from torch's device generator: streams cannot match, the
+// distribution of the result does (tests compare against the exact Normal / Binomial laws).
+__device__ __forceinline__ uint64_t mc_mix(uint64_t z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float mc_u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.f / 16777216.f); }  // (0,1)
+
+struct McParams {
+    const AttrDesc* attrs;
+    const float* P;
+    float* xhat;
+    long long rows;
+    int D, ldp, ldx, learn_std, n;
+    uint64_t seed;
+};
+
+__global__ __launch_bounds__(256) void mc_impute_kernel(McParams p) {
+    const long long total = p.rows * p.D, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long row = i / p.D;
+        const int d = (int)(i - row * p.D);
+        const AttrDesc a = p.attrs[d];
+        const float* pr = p.P + row * p.ldp + a.poff;
+        float* xo = p.xhat + row * p.ldx + a.xoff;
+        const uint64_t key = mc_mix(p.seed ^ mc_mix((uint64_t)i + 0x9E3779B97F4A7C15ull));
+        if (a.type <= 1) {  // Normal(mu, std): mean of n draws
+            const float mu = pr[0], sd = p.learn_std ? sv_softplus(pr[1]) : SV_FIXED_STD;
+            float acc = 0.f;
+            for (int s = 0; s < p.n; s += 2) {  // Box-Muller, two normals per counter
+                const uint64_t r = mc_mix(key + (uint64_t)(s >> 1) * 0xD1342543DE82EF95ull);
+                const float rad = sqrtf(-2.f * logf(mc_u01((uint32_t)r))), ang = 6.283185307179586f * mc_u01((uint32_t)(r >> 32));
+                acc += rad * cosf(ang);
+                if (s + 1 < p.n) acc += rad * sinf(ang);
+            }
+            xo[0] = mu + sd * acc / (float)p.n;
+        } else if (a.type == 2) {  // Bernoulli(logits): round(mean of n draws)
+            const float pb = sv_sigmoid(pr[0]);
+            int cnt = 0;
+            for (int s = 0; s < p.n; s += 2) {
+                const uint64_t r = mc_mix(key + (uint64_t)(s >> 1) * 0xD1342543DE82EF95ull);
+                cnt += mc_u01((uint32_t)r) < pb;
+                if (s + 1 < p.n) cnt += mc_u01((uint32_t)(r >> 32)) < pb;
+            }
+            xo[0] = rintf((float)cnt / (float)p.n);  // torch.round: half to even
+        } else {  // OneHotCategorical(logits [0, theta]): round(mean of n one-hot draws) per class
+            const int C = a.dim;
+            float m = 0.f;
+            for (int c = 1; c < C; ++c) m = fmaxf(m, pr[c - 1]);
+            float se = expf(-m);
+            for (int c = 1; c < C; ++c) se += expf(pr[c - 1] - m);
+            for (int c = 0; c < C; ++c) xo[c] = 0.f;  // counts, then rounded means
+            for (int s = 0; s < p.n; ++s) {
+                const uint64_t r = mc_mix(key + (uint64_t)s * 0xD1342543DE82EF95ull);
+                const float u = mc_u01((uint32_t)r) * se;
+                float cum = expf(-m);
+                int k = 0;
+                while (k + 1 < C && u >= cum) { cum += expf(pr[k] - m); ++k; }
+                xo[k] += 1.f;
+            }
+            for (int c = 0; c < C; ++c) xo[c] = rintf(xo[c] / (float)p.n);
+        }
+    }
+}
+
+int launch_mc_impute(const AttrDesc* attrs_dev, int D, int learn_std, const float* P, int ldp, long long rows,
+                     int n_samples, uint64_t seed, float* xhat, int ldx, hipStream_t stream) {
+    if (rows <= 0) return SHIVAE_OK;
+    McParams p{attrs_dev, P, xhat, rows, D, ldp, ldx, learn_std, n_samples, seed};
+    const int blocks = (int)std::min<long long>((rows * D + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(mc_impute_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
 // ---------------------------------------------------------------- standalone reparameterisation
 // Gumbel-softmax over the K mixture components (samplers.py:28-30, encoders.py:87-88) and the
 // Gaussian z = eps*std + mean (samplers.py:57-62).  One thread per row for the softmaxes.

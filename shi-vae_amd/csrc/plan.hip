@@ -864,6 +864,17 @@ int shivae_heter_nll(shivae_plan* p, const float* x, const uint8_t* mask, const 
                             rowloss, p->X, p->P, p->nll_group, p->nll_xspan, p->nll_pspan, static_cast<hipStream_t>(stream));
 }
 
+int shivae_mc_impute(shivae_plan* p, const float* params, int ldp, int rows, int n_samples, uint64_t seed, float* xhat,
+                     shivae_stream stream) {
+    SV_REQUIRE(p && params && xhat, "mc_impute: null argument");
+    SV_REQUIRE(ldp >= p->P && rows >= 0 && n_samples > 0, "mc_impute: bad sizes");
+    if (!p->attrs_dev) {
+        SV_TRY(upload(p, p->attrs, &p->attrs_dev));
+    }
+    return launch_mc_impute(p->attrs_dev, p->D, p->learn_std, params, ldp, rows, n_samples, seed, xhat, p->X,
+                            static_cast<hipStream_t>(stream));
+}
+
 int shivae_kl_terms(const float* mu_q, const float* std_q, const float* mu_p, const float* std_p, int ldz,
                     const float* s_probs, int ldk, int rows, int Z, int K, float kl_scale, float* dmu_q, float* dstd_q,
                     float* dmu_p, float* dstd_p_pre, float* dlogits, float* rowloss, shivae_stream stream) {

@@ -503,14 +503,18 @@ class ShiVAE(nn.Module):
         return (likes, self.generate_heter_samples(likes)), (z_tup, s_tup)
 
     @torch.no_grad()
-    def generate_heter_samples(self, likes, n_samples=100):
-        """base_missvae.py:378-404: Monte-Carlo means (round for bin/cat), concatenated on the last dim."""
-        cols = []
-        for t in self.types_list:
-            lik = likes[t['name']]
-            m = torch.mean(lik.sample((n_samples,)), dim=0)
-            cols.append(torch.round(m) if t['type'] in ('bin', 'cat') else m)
-        return torch.cat(cols, dim=-1)
+    def generate_heter_samples(self, likes, n_samples=100, seed=None):
+        """base_missvae.py:378-404: Monte-Carlo means (round for bin/cat), concatenated on the last dim -- one HIP
+        pass over the raw likelihood parameters (csrc/loss.hip mc_impute_kernel)."""
+        self._require_gpu()
+        P = self._params_from_likes(likes)
+        T, B, _ = P.shape
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # follows torch.manual_seed
+        xhat = torch.empty(T, B, self.x_dim, dtype=torch.float32, device=P.device)
+        N.check(N.lib().shivae_mc_impute(self._layout.h, N.ptr(P), self.p_dim, T * B, int(n_samples), int(seed),
+                                         N.ptr(xhat), N.stream()))
+        return xhat
 
     @torch.no_grad()
     def impute_mean(self, x, temp=0.01):
