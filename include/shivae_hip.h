@@ -135,6 +135,12 @@ int shivae_elbo_step(shivae_plan* plan, const float* x_dev, const uint8_t* mask_
                      const float* eps_dev, float beta, float temp, float inv_batch, int flags,
                      float* losses_dev, shivae_stream stream);
 
+/* ShiVAE.sample_from_prior (src/models/shivae.py:156-214): generation from the prior over plan.T steps for
+ * plan.B sequences with explicit noise u[T][B][K] (Gumbel uniforms) and eps[T][B][Z].  Afterwards
+ * shivae_get_output gives Z (the prior sample), Z_MEAN / Z_STD (prior mean / std), S, S_PROBS (the uniform
+ * 1/K) and DEC_PARAMS. */
+int shivae_sample_prior(shivae_plan* plan, const float* u_dev, const float* eps_dev, float temp, shivae_stream stream);
+
 /* copy one named output of the last step into dst_dev as [T][B][width] (unpadded) */
 int shivae_get_output(shivae_plan* plan, int which, float* dst_dev, shivae_stream stream);
 int shivae_output_width(const shivae_plan* plan, int which);

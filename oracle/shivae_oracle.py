@@ -312,6 +312,28 @@ class OracleShiVAE:
         # --- decoder (decoders.py:109-176), batched over [T,B], loop over attributes ---
         emb = np.concatenate([c["phi_z"], c["s"], c["h_prev"]], axis=-1)  # decoders.py:127
         c["emb"] = emb
+        dec_params, dec_cache = self._decode(emb)
+        c["dec_params"], c["dec_cache"] = dec_params, dec_cache
+
+        # --- losses (base_missvae.py:166-231) ---
+        nll_type, nll_attr = heter_nll(x, mask, dec_params, self.types_list)
+        klz = kl_q_z(c["mu"], c["std"], mu_p, std_p).sum(axis=(0, 2))
+        kls = kl_q_s(c["probs"]).sum(axis=0)
+        nll = nll_type["real"] + nll_type["pos"] + nll_type["bin"] + nll_type["cat"]
+        beta = dt.type(beta)
+        n_elbo = (nll + beta * klz + beta * kls).mean()
+        c.update(nll_attr=nll_attr, nll_type_b=nll_type, klz_b=klz, kls_b=kls)
+        c["losses"] = dict(n_elbo=n_elbo, nll_loss=nll.mean(), kld=klz.mean() + kls.mean(),
+                           kld_q_z=klz.mean(), kld_q_s=kls.mean(),
+                           nll_real=nll_type["real"].mean(), nll_pos=nll_type["pos"].mean(),
+                           nll_bin=nll_type["bin"].mean(), nll_cat=nll_type["cat"].mean())
+        c.update(x=x, mask=mask, u=u, eps=eps, beta=beta, temp=temp)
+        self.cache = c
+        return c
+
+    def _decode(self, emb):
+        """decoders.py:109-176 on emb = cat[phi_z, s, h_prev]: (per-attribute parameters, activations)."""
+        P, dt = self.P, self.dt
         dec_params, dec_cache = [], []
         for t_ in self.types_list:
             pre = "dec.decoder_dict.%s." % t_["name"]
@@ -339,23 +361,41 @@ class OracleShiVAE:
             else:
                 raise ValueError(ty)
             dec_cache.append(dc)
-        c["dec_params"], c["dec_cache"] = dec_params, dec_cache
+        return dec_params, dec_cache
 
-        # --- losses (base_missvae.py:166-231) ---
-        nll_type, nll_attr = heter_nll(x, mask, dec_params, self.types_list)
-        klz = kl_q_z(c["mu"], c["std"], mu_p, std_p).sum(axis=(0, 2))
-        kls = kl_q_s(c["probs"]).sum(axis=0)
-        nll = nll_type["real"] + nll_type["pos"] + nll_type["bin"] + nll_type["cat"]
-        beta = dt.type(beta)
-        n_elbo = (nll + beta * klz + beta * kls).mean()
-        c.update(nll_attr=nll_attr, nll_type_b=nll_type, klz_b=klz, kls_b=kls)
-        c["losses"] = dict(n_elbo=n_elbo, nll_loss=nll.mean(), kld=klz.mean() + kls.mean(),
-                           kld_q_z=klz.mean(), kld_q_s=kls.mean(),
-                           nll_real=nll_type["real"].mean(), nll_pos=nll_type["pos"].mean(),
-                           nll_bin=nll_type["bin"].mean(), nll_cat=nll_type["cat"].mean())
-        c.update(x=x, mask=mask, u=u, eps=eps, beta=beta, temp=temp)
-        self.cache = c
-        return c
+    def sample_from_prior(self, u, eps, temp=0.02):
+        """shivae.py:156-214 with explicit noise u[T,B,K], eps[T,B,Z]: dict z, mean, std (prior), s, s_probs,
+        dec_params."""
+        P, dt = self.P, self.dt
+        u, eps = np.asarray(u, dtype=dt), np.asarray(eps, dtype=dt)
+        T, B, K = u.shape
+        H, Z = self.H, self.Z
+        temp = dt.type(temp)
+        h, cc = np.zeros((B, H), dtype=dt), np.zeros((B, H), dtype=dt)           # :170-171
+        Wp = P["prior.0.weight"]
+        Wih, Whh = P["rnn.weight_ih_l0"], P["rnn.weight_hh_l0"]
+        bg = P["rnn.bias_ih_l0"] + P["rnn.bias_hh_l0"]
+        out = {k: np.zeros((T, B, d), dtype=dt) for k, d in (("z", Z), ("mean", Z), ("std", Z), ("s", K), ("s_probs", K),
+                                                              ("phi_z", H), ("h_prev", H))}
+        logp = np.log(np.full((B, K), 1.0 / K, dtype=dt))                        # :179-180
+        for t in range(T):
+            s = gumbel_softmax(logp, u[t], temp)
+            pr = relu(h @ Wp[:, :H].T + s @ Wp[:, H:].T + P["prior.0.bias"])     # :184
+            mean = lin(pr, P["prior_mean.weight"], P["prior_mean.bias"])
+            std = softplus(lin(pr, P["prior_std.0.weight"], P["prior_std.0.bias"]))
+            z = reparam(mean, std, eps[t])                                      # :188
+            phi_z = relu(lin(z, P["phi_z.0.weight"], P["phi_z.0.bias"]))         # :194
+            for k, v in (("z", z), ("mean", mean), ("std", std), ("s", s), ("phi_z", phi_z), ("h_prev", h)):
+                out[k][t] = v
+            out["s_probs"][t] = 1.0 / K
+            g4 = phi_z @ Wih.T + h @ Whh.T + bg                                  # :198-199
+            gi, gf = sigmoid(g4[:, :H]), sigmoid(g4[:, H:2 * H])
+            gg, go = np.tanh(g4[:, 2 * H:3 * H]), sigmoid(g4[:, 3 * H:])
+            cc = gf * cc + gi * gg
+            h = go * np.tanh(cc)
+        emb = np.concatenate([out["phi_z"], out["s"], out["h_prev"]], axis=-1)   # :195 dec(phi_z, s, h[-1])
+        out["dec_params"], _ = self._decode(emb)
+        return out
 
     # ---------------------------------------------------------------- backward
     def backward(self, grad_scale=None):

@@ -28,7 +28,7 @@ EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 1
 SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_plan_destroy",
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
            "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
-           "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
+           "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
            "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start",
            "shivae_profile_stop"]
@@ -72,6 +72,7 @@ def lib():
     L.shivae_plan_workspace_bytes.restype = C.c_size_t
     L.shivae_plan_bind.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.shivae_elbo_step.argtypes = [vp, vp, vp, vp, vp, cf, cf, cf, ci, vp, vp]
+    L.shivae_sample_prior.argtypes = [vp, vp, vp, cf, vp]
     L.shivae_get_output.argtypes = [vp, ci, vp, vp]
     L.shivae_output_width.argtypes = [vp, ci]
     L.shivae_get_persum.argtypes = [vp, vp, vp]

@@ -131,6 +131,7 @@ int launch_reparam_bwd(const float* s, const float* ds, int ldk, int K, float te
 struct ScanWOff {
     int xsh, lg, b_lg, e0s, e0h, e2, b_e2, mu, b_mu, sd, b_sd, pz, b_pz, ih, hh, b_g;
     int t_ih, t_hh, t_pz, t_mu, t_sd, t_e2, t_e0s, t_e0h, t_lg, t_xsh;
+    int p0h, p0s, b_p0, pm, b_pm, ps, b_ps;  // prior network (generation scan only)
 };
 
 // Row-major record buffers, row = t*B + b, leading dims padded: Hp/Zp/Kp (multiples of 16),
@@ -160,6 +161,8 @@ struct PackJob {
 
 int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int nb, float* dst, hipStream_t stream);
 int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream);
+// generation from the prior (shivae.py:156-214): writes emb, z, mu(=prior mean), sd(=prior std), probs(=1/K)
+int launch_scan_gen(const ScanArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- misc (optim.hip)
 int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, float* embc, int ldc, int rows,

@@ -285,6 +285,14 @@ static void build_pack_plan(shivae_plan* p, std::vector<PackJob>& wj, std::vecto
     W(w.t_e0h, g[SHIVAE_P_E0_W], H + K, H, Hp, H, Hp, true, 1, 1);
     W(w.t_lg, g[SHIVAE_P_XS2_W], 0, H, Hp, K, Kp, true, 1, 1);
     W(w.t_xsh, g[SHIVAE_P_XS0_W], X, H, Hp, H, Hp, true, 1, 1);
+    // prior network for the generation scan (shivae.py:56-61,184-186)
+    W(w.p0h, g[SHIVAE_P_PRIOR0_W], 0, H, Hp, H, Hp, false, 1, 1);       // prior.0[:, :H] acts on h
+    W(w.p0s, g[SHIVAE_P_PRIOR0_W], H, H, Hp, K, Kp, false, 1, 1);       // prior.0[:, H:] acts on s
+    Bv(w.b_p0, g[SHIVAE_P_PRIOR0_B], nullptr, H, Hp, 1);
+    W(w.pm, g[SHIVAE_P_PRIORMEAN_W], 0, Z, Zp, H, Hp, false, 1, 1);
+    Bv(w.b_pm, g[SHIVAE_P_PRIORMEAN_B], nullptr, Z, Zp, 1);
+    W(w.ps, g[SHIVAE_P_PRIORSTD_W], 0, Z, Zp, H, Hp, false, 1, 1);
+    Bv(w.b_ps, g[SHIVAE_P_PRIORSTD_B], nullptr, Z, Zp, 1);
     (void)E;
     p->wpack_floats = cur;
 }
@@ -660,6 +668,38 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     return SHIVAE_OK;
 }
 
+
+// ShiVAE.sample_from_prior (shivae.py:156-214): generation scan, then the decoder over all rows in chunks.
+static int generate(shivae_plan* p, const float* u, const float* eps, float temp, hipStream_t s) {
+    const int H = p->H, K = p->K, D = p->D, E = p->E, P = p->P;
+    const int Hp = p->Hp, Kp = p->Kp, Ep = p->Ep, E4 = p->E4;
+    const int R = (int)p->R;
+    const Tensor* g = p->glob;
+    const int NT = GEMM_NT;
+    SV_TRY(launch_pack(p->wjobs_dev, p->n_wjobs, p->bjobs_dev, p->n_bjobs, p->wsf("wpack"), s));
+    ScanArgs sa = scan_args(p, u, eps, temp);
+    SV_TRY(launch_scan_gen(sa, s));
+    float *emb = p->wsf("emb"), *embc = p->wsf("embc"), *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
+    const int ldA0 = p->ldA0, ldA1 = p->ldA1, ldHH = p->ldHH;
+    for (int r0 = 0; r0 < R; r0 += p->Rc) {
+        const int rc = std::min(p->Rc, R - r0);
+        SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
+        SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
+                     nullptr, 0, EPI_BIAS | EPI_RELU, s));
+        SV_TRY(gemmg(NT, rc, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s));
+        for (auto& kv : p->f_out) {
+            const int key = kv.first, nout = key < 0 ? -key : key;
+            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s));
+        }
+        SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+    }
+    p->last_flags = SHIVAE_STEP_FORWARD_ONLY | SHIVAE_STEP_KEEP_PARAMS;
+    return SHIVAE_OK;
+}
+
 }  // namespace shivae
 
 // =========================================================================== C ABI
@@ -807,6 +847,16 @@ int shivae_elbo_step(shivae_plan* p, const float* x, const uint8_t* mask, const 
     }
     SV_REQUIRE(temp > 0.f, "elbo_step: temperature must be > 0");
     return step(p, x, mask, u, eps, beta, temp, inv_batch, flags, losses, static_cast<hipStream_t>(stream));
+}
+
+int shivae_sample_prior(shivae_plan* p, const float* u, const float* eps, float temp, shivae_stream stream) {
+    SV_REQUIRE(p && u && eps, "sample_prior: null argument");
+    if (!p->bound) {
+        set_error("sample_prior: plan has no workspace/parameters bound (call shivae_plan_bind)");
+        return SHIVAE_ERR_UNBOUND;
+    }
+    SV_REQUIRE(temp > 0.f, "sample_prior: temperature must be > 0");
+    return generate(p, u, eps, temp, static_cast<hipStream_t>(stream));
 }
 
 int shivae_output_width(const shivae_plan* p, int which) {

@@ -371,6 +371,162 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------- generation
+// ShiVAE.sample_from_prior (shivae.py:156-214): per step  s_t = gumbel_softmax(log(1/K), temp);
+// prior_t = relu(W[h, s] + b); z_t = eps*softplus(Ws prior_t + b) + (Wm prior_t + b); phi_z = relu(Wz z_t + b);
+// LSTM step.  Same tile / operand scheme as the training scan; the decoder runs afterwards over all rows
+// from the emb records [phi_z | s | h_{t-1}].  Records written: emb, z, mu (prior mean), sd (prior std),
+// probs (the uniform prior 1/K, the reference's s_prior_t_probs).
+template <int MAXS, int NTH>
+__global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int Hp = a.Hp, Zp = a.Zp, Kp = a.Kp, Ep = a.Ep, B = a.B;
+    const int HT = Hp >> 4, ZT = Zp >> 4, KT = Kp >> 4;
+    const int bj = blockIdx.x * 16 + j;
+    const bool live = bj < B;
+    float* hb0 = smem;
+    float* hb1 = hb0 + Hp * 16;
+    float* bufA = hb1 + Hp * 16;
+    float* bufB = bufA + Hp * 16;
+    float* sbuf = bufB + Hp * 16;
+    float* zbuf = sbuf + 2 * Kp * 16;
+    const float* Wb = a.wpack;
+    const f32x4 zero4 = {0, 0, 0, 0};
+    const float lq = logf(1.f / (float)a.K);  // torch.log(s_prior_t_probs), shivae.py:179-180
+
+    for (int i = tid; i < Hp * 16; i += blockDim.x) hb0[i] = 0.f;  // shivae.py:170-171 h = c = 0
+    f32x4 creg[MAXS];
+    int own[MAXS];
+    bool ownok[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        creg[s] = zero4;
+        ownok[s] = wid + s * NW < HT;
+        own[s] = ownok[s] ? wid + s * NW : 0;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const size_t row = (size_t)t * B + (live ? bj : 0);
+        const float* h = cur ? hb1 : hb0;
+        float* hn = cur ? hb0 : hb1;
+        // G0: s_t (one thread per sequence; K is small) -- samplers.py:23-30 on constant logits
+        if (tid < 16) {
+            const int jj = tid, bb = blockIdx.x * 16 + jj;
+            const bool lv = bb < B;
+            const size_t r = (size_t)t * B + (lv ? bb : 0);
+            float m2 = -INFINITY;
+            for (int k = 0; k < a.K; ++k) m2 = fmaxf(m2, (lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp);
+            float s2 = 0.f;
+            for (int k = 0; k < a.K; ++k) s2 += expf((lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp - m2);
+            for (int k = 0; k < Kp; ++k) {
+                float sv = 0.f;
+                if (k < a.K) {
+                    sv = expf((lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp - m2) / s2;
+                    if (lv) {
+                        a.emb[r * Ep + Hp + k] = sv;
+                        a.probs[r * Kp + k] = 1.f / (float)a.K;
+                    }
+                }
+                sbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = sv;
+            }
+        }
+        //     meanwhile: the h halves of prior.0 and of the LSTM gates
+        f32x4 pacc[MAXS], g4[MAXS][4];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) pacc[s] = zero4;
+        mma_acc<MAXS>(pacc, Wb + a.w.p0h, HT, own, h, lane);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int nt[4] = {own[s], HT + own[s], 2 * HT + own[s], 3 * HT + own[s]};
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) g4[s][gi] = zero4;
+            if (ownok[s]) mma_acc<4>(g4[s], Wb + a.w.hh, HT, nt, h, lane);
+        }
+        __syncthreads();
+        // G1: prior_t = relu(prior.0 [h, s] + b)             shivae.py:184
+        mma_acc<MAXS>(pacc, Wb + a.w.p0s, KT, own, sbuf, lane);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (ownok[s]) {
+                const int n = own[s] * 16 + 4 * q;
+                st4(bufA + qidx(own[s], q, j), relu4(pacc[s] + ld4(Wb + a.w.b_p0 + n)));
+            }
+        __syncthreads();
+        // G2: prior mean / std, z = eps*std + mean           shivae.py:185-188
+        for (int zt = wid; zt < ZT; zt += NW) {
+            const int nt[1] = {zt};
+            f32x4 am[1] = {zero4}, as[1] = {zero4};
+            mma_acc<1>(am, Wb + a.w.pm, HT, nt, bufA, lane);
+            mma_acc<1>(as, Wb + a.w.ps, HT, nt, bufA, lane);
+            const int n = zt * 16 + 4 * q;
+            const f32x4 mu = am[0] + ld4(Wb + a.w.b_pm + n);
+            const f32x4 sp = as[0] + ld4(Wb + a.w.b_ps + n);
+            f32x4 sd, z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sd[r] = sv_softplus(sp[r]);
+                const float e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
+                z[r] = e * sd[r] + mu[r];
+            }
+            st4(zbuf + qidx(zt, q, j), z);
+            if (live) {
+                st4(a.mu + row * Zp + n, mu);
+                st4(a.sd + row * Zp + n, sd);
+                st4(a.z + row * Zp + n, z);
+            }
+        }
+        __syncthreads();
+        // G3: phi_z = relu(Wz z + b)                         shivae.py:194
+        {
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.pz, ZT, own, zbuf, lane);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const int n = own[s] * 16 + 4 * q;
+                    const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_pz + n));
+                    st4(bufB + qidx(own[s], q, j), v);
+                    if (live) st4(a.emb + row * Ep + n, v);
+                }
+        }
+        __syncthreads();
+        // G4: LSTM cell                                      shivae.py:198-199
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            if (ownok[s]) {
+                const int ht = own[s];
+                const int nt[4] = {ht, HT + ht, 2 * HT + ht, 3 * HT + ht};
+                mma_acc<4>(g4[s], Wb + a.w.ih, HT, nt, bufB, lane);
+                const int n = ht * 16 + 4 * q;
+#pragma unroll
+                for (int gidx = 0; gidx < 4; ++gidx) g4[s][gidx] += ld4(Wb + a.w.b_g + gidx * Hp + n);
+                f32x4 cn, hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gi = sv_sigmoid(g4[s][0][r]), gf = sv_sigmoid(g4[s][1][r]);
+                    const float gg = tanhf(g4[s][2][r]), go = sv_sigmoid(g4[s][3][r]);
+                    cn[r] = gf * creg[s][r] + gi * gg;
+                    hv[r] = go * tanhf(cn[r]);
+                }
+                creg[s] = cn;
+                st4(hn + qidx(ht, q, j), hv);
+                if (live) {
+                    if (t == 0) st4(a.emb + row * Ep + Hp + Kp + n, zero4);  // h_{-1} = 0 record of the first step
+                    if (t + 1 < a.T) st4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------- backward
 template <int MAXS, int NTH>
 __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
@@ -672,6 +828,40 @@ int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream) {
         case 2: return launch_scan_t<2, 256>(a, bwd, nw, stream);
         case 4: return launch_scan_t<4, 256>(a, bwd, nw, stream);
         default: return launch_scan_t<8, 256>(a, bwd, nw, stream);
+    }
+}
+
+template <int MAXS, int NTH>
+static int launch_gen_t(const ScanArgs& a, int nw, hipStream_t stream) {
+    const size_t lds = sizeof(float) * 16 * (4 * a.Hp + 2 * a.Kp + a.Zp);
+    SV_REQUIRE(lds <= 160 * 1024, "scan: needs %zu B of LDS (> 160 KiB)", lds);
+    auto kern = scan_gen_kernel<MAXS, NTH>;
+    if (lds > 64 * 1024)
+        SV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.B, 16)), dim3(nw * 64), lds, stream, a);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+int launch_scan_gen(const ScanArgs& a, hipStream_t stream) {
+    if (a.T <= 0 || a.B <= 0) return SHIVAE_OK;
+    int nw, maxs;
+    SV_TRY(scan_geometry(a, nw, maxs));
+    if (nw > 4) {  // generation is not a hot path: one register budget (<= 8 waves) covers every geometry
+        nw = 8;
+        maxs = ceil_div(a.Hp / 16, nw) <= 1 ? 1 : ceil_div(a.Hp / 16, nw) <= 2 ? 2 : 4;
+        switch (maxs) {
+            case 1: return launch_gen_t<1, 512>(a, nw, stream);
+            case 2: return launch_gen_t<2, 512>(a, nw, stream);
+            default: return launch_gen_t<4, 512>(a, nw, stream);
+        }
+    }
+    switch (maxs) {
+        case 1: return launch_gen_t<1, 256>(a, nw, stream);
+        case 2: return launch_gen_t<2, 256>(a, nw, stream);
+        case 4: return launch_gen_t<4, 256>(a, nw, stream);
+        default: return launch_gen_t<8, 256>(a, nw, stream);
     }
 }
 

@@ -531,12 +531,41 @@ class ShiVAE(nn.Module):
                 cols.append(torch.nn.functional.one_hot(lik.logits.argmax(-1), int(t['dim'])).float())
         return torch.cat(cols, dim=-1)
 
+    @torch.no_grad()
     def sample_from_prior(self, batch_size, ts, temp=0.02):
-        raise NotImplementedError("generation from the prior (shivae.py:156-214) is outside the accelerated train/"
-                                  "imputation path (SURVEY.md 8f, row f4)")
+        """shivae.py:156-214: (z_prior_tup, s_tup, likes) generated from the prior, as one HIP scan + the batched
+        decoder (csrc/scan.hip scan_gen_kernel).  Noise: ``set_noise(u, eps)`` or ``noise_mode``."""
+        self._require_gpu()
+        dev = self._flat.device
+        T, B = int(ts), int(batch_size)
+        u, eps = self._draw_noise(T, B)
+        O, L = N.O, N.lib()
+        bm = self.micro_batch(T, B)
+        if bm < B:
+            nmb = -(-B // bm)
+            bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
+        want = [O["Z"], O["Z_MEAN"], O["Z_STD"], O["S"], O["S_PROBS"], O["DEC_PARAMS"]]
+        outs = {w: [] for w in want}
+        for b0 in range(0, B, bm):
+            b1 = min(B, b0 + bm)
+            plan = self._activate(T, b1 - b0)
+            us, es = (u, eps) if (b0 == 0 and b1 == B) else (u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous())
+            N.check(L.shivae_sample_prior(plan.h, N.ptr(us), N.ptr(es), float(temp), N.stream()))
+            for w in want:
+                o = torch.empty(T, b1 - b0, plan.output_width(w), dtype=torch.float32, device=dev)
+                N.check(L.shivae_get_output(plan.h, w, N.ptr(o), N.stream()))
+                outs[w].append(o)
+        o = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
+        z_prior_tup = [o[O["Z"]], o[O["Z_MEAN"]], o[O["Z_STD"]]]
+        s_tup = [o[O["S"]], o[O["S_PROBS"]]]
+        self._last = dict(u=u, eps=eps, persum=None, dec_params=o[O["DEC_PARAMS"]])
+        return z_prior_tup, s_tup, self._likes_from_params(o[O["DEC_PARAMS"]])
 
+    @torch.no_grad()
     def sample(self, batch_size, ts, temp=0.01):
-        return self.sample_from_prior(batch_size, ts, temp)
+        """base_missvae.py:361-376: ((likes, x_hat), z_prior_tup, s_tup)."""
+        z_prior_tup, s_tup, likes = self.sample_from_prior(batch_size, ts, temp)
+        return (likes, self.generate_heter_samples(likes)), z_prior_tup, s_tup
 
     # ------------------------------------------------------------------ data parallel
     def allreduce_grads(self):

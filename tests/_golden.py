@@ -6,7 +6,7 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-               if not os.path.basename(p).startswith(("scaler_", "metrics_")))
+               if not os.path.basename(p).startswith(("scaler_", "metrics_", "gen_")))
 
 
 def load(name):
