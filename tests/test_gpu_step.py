@@ -115,6 +115,14 @@ CASES = {
     "ragged_chunks": (shivae_amd.utils.make_types_list(2, 2, 1, [3]), 11, 21, 20, 5, 4, True, 0.5, 64),
     "h80_multiwave": (shivae_amd.utils.make_types_list(1, 1, 1, [5]), 6, 18, 80, 24, 6, False, 0.3, 0),
     "cat_heavy_miss90": (shivae_amd.utils.make_types_list(1, 1, 1, [8] * 7), 8, 19, 24, 8, 8, True, 0.9, 0),
+    # edge cases: K > 16 (two k tiles: unfused logits/softmax stage), a single timestep, a single attribute type,
+    # every entry missing, 16 waves per scan workgroup (H = 256) with the 128x128 GEMM tiles and fused bias sums
+    "k20_two_ktiles": (shivae_amd.utils.make_types_list(2, 1, 1, [3]), 5, 17, 32, 6, 20, True, 0.3, 0),
+    "single_timestep": (shivae_amd.utils.make_types_list(1, 1, 1, [4]), 1, 33, 16, 3, 3, True, 0.3, 0),
+    "only_real": (shivae_amd.utils.make_types_list(5, 0, 0, []), 7, 9, 16, 4, 3, False, 0.2, 0),
+    "only_cat": (shivae_amd.utils.make_types_list(0, 0, 0, [2, 3, 9]), 7, 9, 16, 4, 3, True, 0.2, 0),
+    "all_missing": (shivae_amd.utils.make_types_list(1, 1, 1, [3]), 6, 8, 16, 4, 3, True, 1.0, 0),
+    "h256_16waves": (shivae_amd.utils.make_types_list(1, 1, 1, [3]), 4, 40, 256, 64, 16, True, 0.3, 0),
 }
 
 
