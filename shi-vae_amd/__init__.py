@@ -6,5 +6,6 @@ from .shivae import ShiVAE, LOSS_KEYS  # noqa: F401
 from .optim import FusedClipAdam  # noqa: F401
 from .trainers import Trainer, KL_Annealing, LinearTempScheduler  # noqa: F401
 from .scalers import HeterogeneousScaler  # noqa: F401
+from . import datasets, metrics  # noqa: F401
 
 __all__ = ["ShiVAE", "FusedClipAdam", "Trainer", "HeterogeneousScaler", "LOSS_KEYS", "utils"]
