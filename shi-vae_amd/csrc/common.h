@@ -84,6 +84,8 @@ struct GemmDesc {
     int c_aligned;  // 1: every group's C (and aux) base is 16-B aligned (group tables; inline groups are checked)
 };
 
+extern unsigned long long* g_gemm_stamps;  // diagnostics: see shivae_debug_gemm_stamps
+
 // groups_dev: device array of ngroups GemmGroup, or nullptr with ngroups==1 and g0 used.
 int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
                 hipStream_t stream);

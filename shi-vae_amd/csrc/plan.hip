@@ -1003,6 +1003,12 @@ int shivae_profile_stop(double* out, int max_entries) {
     return n;
 }
 
+/* diagnostics (tools/gemm_stamps.py): 4 s_memtime stamps per workgroup of the following GEMM launches, or NULL */
+int shivae_debug_gemm_stamps(unsigned long long* buf_dev) {
+    shivae::g_gemm_stamps = buf_dev;
+    return SHIVAE_OK;
+}
+
 int shivae_zero(float* buf, int64_t n, shivae_stream stream) {
     SV_REQUIRE(buf && n >= 0, "zero: bad argument");
     SV_CHECK_HIP(hipMemsetAsync(buf, 0, (size_t)n * sizeof(float), static_cast<hipStream_t>(stream)));
