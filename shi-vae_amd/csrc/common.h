@@ -53,7 +53,13 @@ struct GemmGroup {
     const float* bias;  // [N] or null
     const float* aux;   // [M,N] activation whose sign gates the output (ReLU backward) or null
     float* csum;        // [N] column sums of the stored C are ADDED here (EPI_COLSUM: bias gradient) or null
+    // Ragged rows (GemmDesc::ragged selects which of these a launch honours; all default to null):
+    const int* cnt;     // device int: this group's live row count -- M for NT / NN, K for TN (RAG_CNT)
+    const int* aidx;    // A is read through a row list: row i (NT/NN) or k-row i (TN) comes from A row aidx[i] (RAG_AIDX)
+    const int* bidx;    // TN only: k-row i of B comes from B row bidx[i] (RAG_BIDX)
+    const int* cidx;    // NT / NN: row i of the result is stored to C row cidx[i]; aux stays row i (RAG_CIDX)
 };
+enum GemmRagged { RAG_CNT = 1, RAG_AIDX = 2, RAG_BIDX = 4, RAG_CIDX = 8 };
 
 enum GemmLayout {
     // C[M,N] = A[M,K] * B[N,K]^T   (forward linear: activations x weight[out,in])
@@ -82,6 +88,7 @@ struct GemmDesc {
     int splitk;     // >=1; >1 requires EPI_ATOMIC
     int unaligned;  // 1: some group base pointer is not 16-B aligned -> scalar global loads
     int c_aligned;  // 1: every group's C (and aux) base is 16-B aligned (group tables; inline groups are checked)
+    int ragged;     // GemmRagged bits: per-group device-side row counts and row lists (the mask-aware decoder)
 };
 
 extern unsigned long long* g_gemm_stamps;  // diagnostics: see shivae_debug_gemm_stamps
@@ -97,6 +104,12 @@ struct ColsumGroup {
 };
 int launch_colsum(int M, int N, int ld, const ColsumGroup* groups_dev, int ngroups,
                   const ColsumGroup& g0, hipStream_t stream);
+
+struct AttrDesc;
+// Row lists of the mask-aware decoder: for every attribute d, idx[d*ld_idx + i] = i-th row (ascending) of the
+// chunk in which the attribute is observed, cnt[d] = how many (base_missvae.py:271-274 picks the mask column).
+int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, int* idx,
+                         int ld_idx, int* cnt, hipStream_t stream);
 
 
 // ---------------------------------------------------------------- loss kernels (loss.hip)

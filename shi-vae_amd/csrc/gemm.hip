@@ -35,11 +35,34 @@ struct TileLoader {
     // !KC: global X[k*ld + row]
     // Loads are UNCONDITIONAL (out-of-range lanes read X[0] and are zeroed by a select): a branch
     // around a load makes hipcc wait vmcnt(0) per element and serialises the whole tile fetch.
+    //
+    // Row lists (ragged launches): the operand's rows -- tile rows for KC, k-rows for !KC -- may come through an
+    // index list.  src[i] is the source row of this thread's piece i: fixed over the K loop for KC; for !KC it is
+    // the k-row of the NEXT load() and is refreshed one K-tile ahead, so the index fetch never sits between a
+    // load() and its data.
     static constexpr int NV = ROWS * 8 / NT;  // float4 per thread
     float4 v[NV > 0 ? NV : 1];
+    int src[NV > 0 ? NV : 1];
+
+    // (the list is read unconditionally -- without a list, a dummy word of the operand itself -- and selected
+    // afterwards: a branch around the load would put a full vmcnt(0) wait into the K loop)
+    __device__ __forceinline__ static int pick(const int* __restrict__ idx, const float* __restrict__ X, int i, int lim) {
+        const int* q = idx ? idx : reinterpret_cast<const int*>(X);
+        const int t = q[(idx && i < lim) ? i : 0];
+        return idx ? t : i;
+    }
+
+    __device__ __forceinline__ void init(const int* __restrict__ idx, const float* __restrict__ X, int row0, int nrows,
+                                         int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * NT;
+            src[i] = KC ? pick(idx, X, row0 + (f >> 3), nrows) : pick(idx, X, k0 + f / (ROWS / 4), kend);
+        }
+    }
 
     __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int row0, int nrows, int k0,
-                                         int kend, int tid) {
+                                         int kend, int tid, const int* __restrict__ idx) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = tid + i * NT;
@@ -47,7 +70,7 @@ struct TileLoader {
             if (KC) { r = f >> 3; k = (f & 7) * 4; }
             else    { k = f / (ROWS / 4); r = (f % (ROWS / 4)) * 4; }
             const int gr = row0 + r, gk = k0 + k;
-            const size_t off = KC ? (size_t)gr * ld + gk : (size_t)gk * ld + gr;
+            const size_t off = KC ? (size_t)src[i] * ld + gk : (size_t)src[i] * ld + gr;
             if (VEC) {  // contiguous extent is a multiple of 4: a float4 is all-valid or all-invalid
                 const bool ok = gr < nrows && gk < kend;
                 const float4 x = *reinterpret_cast<const float4*>(X + (ok ? off : 0));
@@ -62,6 +85,10 @@ struct TileLoader {
                 }
                 v[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
+        }
+        if (!KC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) src[i] = pick(idx, X, k0 + 32 + (tid + i * NT) / (ROWS / 4), kend);
         }
     }
 
@@ -122,7 +149,7 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int s, in
 }
 
 struct GemmParams {
-    int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB, vecC;
+    int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB, vecC, ragged;
     // tile -> workgroup map (see tile_coords): tile counts, super-tile shape (SX*SY*SZ = 64), super-tile counts
     int ntx, nty, ntz, SX, SY, SZ, cx, cy, nsuper, nlin;
     unsigned long long* stamps;  // diagnostics: 4 s_memtime stamps per workgroup (tools/gemm_stamps.py), else null
@@ -155,7 +182,7 @@ __device__ __forceinline__ bool tile_coords(const GemmParams& p, int lin, int& b
 // use scalar loads (SGPR pointers) wherever it is read, also after stores to C.
 __device__ __forceinline__ GemmGroup load_group(const GemmParams& p, int gi) {
     if (!p.groups) return p.g0;
-    static_assert(sizeof(GemmGroup) == 6 * sizeof(void*), "GemmGroup is six pointers");
+    static_assert(sizeof(GemmGroup) == 10 * sizeof(void*), "GemmGroup is ten pointers");
     typedef const unsigned long long __attribute__((address_space(4))) * const_u64_ptr;
     const_u64_ptr q = (const_u64_ptr)(uintptr_t)(p.groups + __builtin_amdgcn_readfirstlane(gi));
     GemmGroup g;
@@ -165,6 +192,10 @@ __device__ __forceinline__ GemmGroup load_group(const GemmParams& p, int gi) {
     g.bias = reinterpret_cast<const float*>(q[3]);
     g.aux = reinterpret_cast<const float*>(q[4]);
     g.csum = reinterpret_cast<float*>(q[5]);
+    g.cnt = reinterpret_cast<const int*>(q[6]);
+    g.aidx = reinterpret_cast<const int*>(q[7]);
+    g.bidx = reinterpret_cast<const int*>(q[8]);
+    g.cidx = reinterpret_cast<const int*>(q[9]);
     return g;
 }
 
@@ -192,8 +223,28 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     const int gidx = bz / p.splitk, ks = bz % p.splitk;
     const GemmGroup g = load_group(p, gidx);
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = ks * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
+    int kchunk = p.kchunk;
+    // Ragged launch: the group's live extent is a device-side count (rows of C for NT / NN, K for TN) and rows may
+    // go through index lists.  Tiles wholly past the count leave at once (uniform per workgroup).
+    int Mrows = p.M, Kext = p.K;
+    const int *aidx = nullptr, *bidx = nullptr, *cidx = nullptr;
+    if (p.ragged) {
+        if (p.ragged & RAG_CNT) {
+            typedef const int __attribute__((address_space(4))) * const_int_ptr;
+            const int c = *(const_int_ptr)(uintptr_t)g.cnt;
+            if (A_KC) Mrows = min(Mrows, c);
+            else {  // split the LIVE K evenly over the K-splits (whole K-tiles)
+                Kext = min(Kext, c);
+                kchunk = ((Kext + p.splitk - 1) / p.splitk + 31) & ~31;
+            }
+        }
+        if (p.ragged & RAG_AIDX) aidx = g.aidx;
+        if (p.ragged & RAG_BIDX) bidx = g.bidx;
+        if (p.ragged & RAG_CIDX) cidx = g.cidx;
+    }
+    const int kbeg = ks * kchunk;
+    if (p.ragged && (m0 >= Mrows || kbeg >= Kext)) return;  // (TN ragged launches are atomic: nothing to add)
+    const int kend = min(Kext, kbeg + kchunk);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -205,6 +256,10 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
 
     TileLoader<A_KC, BM, NT, VEC> la;
     TileLoader<B_KC, BN, NT, VEC> lb;
+    if constexpr (!DMA) {
+        la.init(aidx, g.A, m0, Mrows, kbeg, kend, tid);
+        lb.init(bidx, g.B, n0, p.N, kbeg, kend, tid);
+    }
     auto compute = [&](const float* sa, const float* sb) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -249,8 +304,8 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         }
     } else if constexpr (DB) {
         if (kbeg < kend) {
-            la.load(g.A, p.lda, m0, p.M, kbeg, kend, tid);
-            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid);
+            la.load(g.A, p.lda, m0, Mrows, kbeg, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid, bidx);
         }
         // two LDS stages, one barrier per K-tile: the next tile's registers are parked in the other
         // stage after this tile's MFMAs, so the global-load latency hides behind them
@@ -262,8 +317,8 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
             const bool more = k0 + 32 < kend;
             if (more) {
-                la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
-                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+                la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
+                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
             }
             compute(ldsA + cur * STAGE, ldsB + cur * STAGE);
             if (more) {
@@ -275,16 +330,16 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         }
     } else {
         if (kbeg < kend) {
-            la.load(g.A, p.lda, m0, p.M, kbeg, kend, tid);
-            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid);
+            la.load(g.A, p.lda, m0, Mrows, kbeg, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid, bidx);
         }
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
             la.store(ldsA, tid);
             lb.store(ldsB, tid);
             __syncthreads();
             if (k0 + 32 < kend) {
-                la.load(g.A, p.lda, m0, p.M, k0 + 32, kend, tid);
-                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+                la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
+                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
             }
             compute(ldsA, ldsB);
             __syncthreads();
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                         const int lr = (tid + i * NT) / (BN / 4);
                         const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
                         ax[i] = *reinterpret_cast<const float4*>(
-                            g.aux + ((colok && row < p.M) ? (size_t)row * p.ldaux + col : 0));
+                            g.aux + ((colok && row < Mrows) ? (size_t)row * p.ldaux + col : 0));
                     }
                 }
 #pragma unroll
@@ -351,8 +406,9 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                     for (int i = 0; i < CH; ++i) {
                         const int lr = (tid + (i0 + i) * NT) / (BN / 4);
                         const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
-                        ok[i] = colok && row < p.M;
-                        off[i] = ok[i] ? (size_t)row * p.ldc + col : 0;
+                        ok[i] = colok && row < Mrows;
+                        const int crow = cidx ? cidx[ok[i] ? row : 0] : row;
+                        off[i] = ok[i] ? (size_t)crow * p.ldc + col : 0;
                         v[i] = *reinterpret_cast<const float4*>(lds + lr * LDE + c4 * 4);
                         if (epi & EPI_ADDC) cold[i] = *reinterpret_cast<const float4*>(g.C + off[i]);
                         if (!PF && (epi & EPI_MASK))
@@ -424,8 +480,8 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                float* cp = g.C + (size_t)row * p.ldc + col;
+                if (row >= Mrows) continue;
+                float* cp = g.C + (size_t)(cidx ? cidx[row] : row) * p.ldc + col;
                 float v = acc[x][y][r];
                 if (epi & EPI_ATOMIC) {
                     atomicAdd(cp, v);
@@ -499,7 +555,7 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
         // LDS-DMA staging needs whole K-tiles (no zero fill) and at least one 16-B piece per clamped row.
         // Measured in the training step (B=256, T=100): TN +1.3 %, NN +3 %, NT -1.7 % -> NT keeps the register path.
         static const int dma = [] { const char* f = getenv("SHIVAE_GEMM_DMA"); return f ? atoi(f) : 1; }();
-        if (dma && mode != 3 && p.K % 32 == 0 && p.M >= 4 && p.N >= 4)
+        if (dma && mode != 3 && !p.ragged && p.K % 32 == 0 && p.M >= 4 && p.N >= 4)
             return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, true, true>(p, ngroups, stream);    // 128 x 128, 8 waves, LDS-DMA
     }
     return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, true>(p, ngroups, stream);                  // 128 x 128, 8 waves
@@ -522,7 +578,11 @@ int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, con
     GemmParams p;
     p.M = d.M; p.N = d.N; p.K = d.K;
     p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux;
-    p.epi = d.epi; p.splitk = d.splitk;
+    p.epi = d.epi; p.splitk = d.splitk; p.ragged = d.ragged;
+    SV_REQUIRE(!d.ragged || groups_dev != nullptr, "gemm: ragged launches take a device group table");
+    SV_REQUIRE(!d.ragged || d.layout != GEMM_TN || d.epi == EPI_ATOMIC, "gemm: a ragged TN launch adds atomically");
+    SV_REQUIRE(!(d.ragged & RAG_BIDX) || d.layout == GEMM_TN, "gemm: a B row list is for TN");
+    SV_REQUIRE(!(d.ragged & RAG_CIDX) || d.layout != GEMM_TN, "gemm: a C row list is for NT / NN");
     p.kchunk = round_up(ceil_div(d.K > 0 ? d.K : 1, d.splitk), 32);
     p.groups = groups_dev; p.g0 = g0;
     const bool a_kc = d.layout != GEMM_TN, b_kc = d.layout == GEMM_NT;

@@ -49,13 +49,13 @@ __global__ __launch_bounds__(256) void heter_nll_kernel(NllParams p) {
                     float dmu, dsd;
                     nll = sv_nll_normal(xr[a.xoff], mu, sd, dmu, dsd);
                     if (p.want_grad) {
-                        dr[a.poff] = dmu * g;
-                        if (p.learn_std) dr[a.poff + 1] = dsd * g * sv_softplus_grad_from_out(sd);
+                        dr[a.poff] = obs ? dmu * g : 0.f;
+                        if (p.learn_std) dr[a.poff + 1] = obs ? dsd * g * sv_softplus_grad_from_out(sd) : 0.f;
                     }
                 } else if (a.type == 2) {  // bin: Bernoulli(logits)
                     float dl;
                     nll = sv_nll_bernoulli(xr[a.xoff], pr[a.poff], dl);
-                    if (p.want_grad) dr[a.poff] = dl * g;
+                    if (p.want_grad) dr[a.poff] = obs ? dl * g : 0.f;
                 } else {  // cat: OneHotCategorical(logits = [0, theta_1..theta_{C-1}])
                     const int C = a.dim;
                     float m = 0.f, xbest = xr[a.xoff];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void heter_nll_kernel(NllParams p) {
                         const float inv = 1.f / se;
                         for (int c = 1; c < C; ++c) {
                             const float sm = expf(pr[a.poff + c - 1] - m) * inv;
-                            dr[a.poff + c - 1] = (sm - (c == idx ? 1.f : 0.f)) * g;
+                            dr[a.poff + c - 1] = obs ? (sm - (c == idx ? 1.f : 0.f)) * g : 0.f;
                         }
                     }
                 }
@@ -178,13 +178,13 @@ __global__ __launch_bounds__(256, 6) void heter_nll_stream_kernel(NllStreamParam
                     float dmu, dsd;
                     nll = FAST ? sv_nll_normal_fast(xr[0], mu, sd, dmu, dsd) : sv_nll_normal(xr[0], mu, sd, dmu, dsd);
                     if (p.want_grad) {
-                        pr[0] = dmu * g;
-                        if (p.learn_std) pr[1] = dsd * g * (FAST ? sv_softplus_grad_from_out_fast(sd) : sv_softplus_grad_from_out(sd));
+                        pr[0] = obs ? dmu * g : 0.f;
+                        if (p.learn_std) pr[1] = obs ? dsd * g * (FAST ? sv_softplus_grad_from_out_fast(sd) : sv_softplus_grad_from_out(sd)) : 0.f;
                     }
                 } else if (type == 2) {  // bin: Bernoulli(logits)
                     float dl;
                     nll = FAST ? sv_nll_bernoulli_fast(xr[0], pr[0], dl) : sv_nll_bernoulli(xr[0], pr[0], dl);
-                    if (p.want_grad) pr[0] = dl * g;
+                    if (p.want_grad) pr[0] = obs ? dl * g : 0.f;
                 } else {  // cat: OneHotCategorical(logits = [0, theta_1..theta_{C-1}])
                     float m = 0.f, xbest = xr[0], tsel = 0.f;
                     int idx = 0;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 6) void heter_nll_stream_kernel(NllStreamParam
                     if (p.want_grad) {
                         const float inv = FAST ? sv_frcp(se) : 1.f / se;
 #pragma unroll 4
-                        for (int c = 1; c < dim; ++c) pr[c - 1] = (pr[c - 1] * inv - (c == idx ? 1.f : 0.f)) * g;
+                        for (int c = 1; c < dim; ++c) pr[c - 1] = obs ? (pr[c - 1] * inv - (c == idx ? 1.f : 0.f)) * g : 0.f;
                     }
                 }
                 const float v = obs ? nll : 0.f;
@@ -651,6 +651,50 @@ int launch_reparam_bwd(const float* s, const float* ds, int ldk, int K, float te
     if (rows <= 0) return SHIVAE_OK;
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, stream, s, ds, ldk, K, temp,
                        dlogits, eps, dz, ldz, Z, dmean, dsd, rows);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// ---------------------------------------------------------------- observed-row lists (mask-aware decoder)
+// A missing attribute has no likelihood term (base_missvae.py:271-285: nll * mask), so nothing flows into its
+// decoder network from that row: the decoder only has to run on the rows in which the attribute is observed.
+// One workgroup per attribute compacts the chunk's row numbers in ascending order (ballot + popcount inside a
+// wave, wave totals through LDS), which keeps every downstream summation order fixed by the data alone.
+__global__ __launch_bounds__(1024) void observed_rows_kernel(const AttrDesc* __restrict__ attrs, const uint8_t* __restrict__ mask,
+                                                             int ldm, int rows, int* __restrict__ idx, int ld_idx,
+                                                             int* __restrict__ cnt) {
+    __shared__ int wtot[16];
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const AttrDesc a = attrs[d];
+    const int col = a.xoff + a.dim - 1;
+    int* out = idx + (size_t)d * ld_idx;
+    int run = 0;
+    for (int base = 0; base < rows; base += 1024) {
+        const int row = base + tid;
+        const bool obs = row < rows && mask[(size_t)row * ldm + col] == 0;
+        const unsigned long long b = __ballot(obs);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wid] = __popcll(b);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int t = wtot[w];
+            woff += w < wid ? t : 0;
+            tot += t;
+        }
+        if (obs) out[run + woff + before] = row;
+        run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) cnt[d] = run;
+}
+
+int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, int* idx,
+                         int ld_idx, int* cnt, hipStream_t stream) {
+    if (D <= 0) return SHIVAE_OK;
+    SV_REQUIRE(rows >= 0 && rows <= ld_idx, "observed_rows: %d rows exceed the list stride %d", rows, ld_idx);
+    hipLaunchKernelGGL(observed_rows_kernel, dim3(D), dim3(1024), 0, stream, attrs_dev, mask, ldm, rows, idx, ld_idx, cnt);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
 }

@@ -27,19 +27,30 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- HIP-event profiler: one (start, stop) pair per launch, resolved when the caller collects
-struct ProfRec { int id; double work; hipEvent_t a, b; int M, N, K, G; };
+// A ragged GEMM launch (mask-aware decoder) only multiplies the observed rows of every group: its work is the dense
+// figure scaled by sum(cnt[attr of group]) / (groups * extent).  The counts live on the device; while profiling,
+// each chunk's counts are copied to a pinned host block and the record keeps a pointer to it.
+struct ProfRec { int id; double work; hipEvent_t a, b; int M, N, K, G; const std::vector<int>* rag_attr; const int* rag_cnt; int rag_ext; };
 static int g_pm = 0, g_pn = 0, g_pk = 0, g_pg = 0;
 void prof_shape(int M, int N, int K, int G) { g_pm = M; g_pn = N; g_pk = K; g_pg = G; }
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::vector<int*> g_prof_cnt_blocks;  // pinned, one per chunk while profiling
+static const std::vector<int>* g_rag_attr = nullptr;
+static const int* g_rag_cnt = nullptr;
+static int g_rag_ext = 0;
+static void prof_ragged(const std::vector<int>* attr, const int* cnt_host, int ext) { g_rag_attr = attr; g_rag_cnt = cnt_host; g_rag_ext = ext; }
 void prof_begin(int id, double work, hipStream_t s) {
     if (!g_prof_on) return;
-    ProfRec r{id, work, nullptr, nullptr, g_pm, g_pn, g_pk, g_pg};
+    ProfRec r{id, work, nullptr, nullptr, g_pm, g_pn, g_pk, g_pg, g_rag_attr, g_rag_cnt, g_rag_ext};
     g_pm = g_pn = g_pk = g_pg = 0;
+    g_rag_attr = nullptr; g_rag_cnt = nullptr; g_rag_ext = 0;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
 }
+static bool prof_on() { return g_prof_on; }
+static void prof_keep_block(int* blk) { g_prof_cnt_blocks.push_back(blk); }
 void prof_end(hipStream_t s) {
     if (!g_prof_on || g_prof.empty()) return;
     (void)hipEventRecord(g_prof.back().b, s);
@@ -55,6 +66,7 @@ struct GroupTable {  // device table of GemmGroup + matching bias-gradient table
     int n = 0;
     int unaligned = 0;
     int c_aligned = 1;
+    std::vector<int> attr;  // attribute of each group (ragged launches: whose row count applies)
 };
 struct ColTable {
     ColsumGroup* dev = nullptr;
@@ -94,7 +106,10 @@ struct shivae_plan {
     size_t wpack_floats = 0;
     std::vector<void*> owned;  // device allocations to free
     // grouped-GEMM tables
-    GroupTable f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
+    GroupTable b_l0_w, b_l0_wr;  // layer-0 weight gradient per attribute (ragged steps): main columns + the E % 128 remainder
+    int l0_nmain = 0;
+    GroupTable f_l0, f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
+    int compact = 1;  // mask-aware decoder in training steps (SHIVAE_COMPACT=0: dense)
     std::map<int, GroupTable> f_out, b_out_w, b_out_d;  // keyed by nout
     std::map<int, ColTable> c_out;
 
@@ -215,6 +230,8 @@ static void build_workspace(shivae_plan* p) {
     carve(p, "hh", Rc * p->ldHH, cur);
     carve(p, "dhh", Rc * p->ldHH, cur);
     carve(p, "pbuf", Rc * p->P, cur);
+    carve(p, "rowidx", D * Rc, cur);  // int: per attribute, the chunk's observed rows (launch_observed_rows)
+    carve(p, "rowcnt", D, cur);       // int: how many
     carve(p, "wpack", p->wpack_floats, cur);
     // K-contiguous (transposed) copies of the decoder weights for the input-gradient GEMMs
     carve(p, "wt0", (size_t)p->E * D * 2 * H, cur);
@@ -307,8 +324,10 @@ static int upload(shivae_plan* p, const std::vector<T>& host, T** dev) {
     return SHIVAE_OK;
 }
 
-static int make_table(shivae_plan* p, const std::vector<GemmGroup>& g, GroupTable& t) {
+static int make_table(shivae_plan* p, const std::vector<GemmGroup>& g, GroupTable& t,
+                      const std::vector<int>& attr = std::vector<int>()) {
     t.n = (int)g.size();
+    t.attr = attr;
     t.unaligned = 0;
     t.c_aligned = 1;
     for (const GemmGroup& x : g)
@@ -329,21 +348,47 @@ static int build_tables(shivae_plan* p) {
     float *da0 = p->wsf("da0"), *da1 = p->wsf("da1"), *da2 = p->wsf("da2"), *dhh = p->wsf("dhh");
     auto PA = [&](int id, int d) { return p->params + p->per_attr[id][d].off; };
     auto GA = [&](int id, int d) { return p->grads + p->per_attr[id][d].off; };
-    std::vector<GemmGroup> fl1, fl2, fh0, wl1, dl1, wl2, dl2, wh0, dh0;
+    // Row lists of the mask-aware decoder (launch_observed_rows): every group carries its attribute's count and
+    // list; a launch says through GemmDesc::ragged which of them it honours, so one table serves both forms.
+    int* rowidx = reinterpret_cast<int*>(p->wsf("rowidx"));
+    int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
+    const float* embc = p->wsf("embc");
+    std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, wl1, dl1, wl2, dl2, wh0, dh0;
+    {
+        // a few columns past a multiple of 128 (E = 528) go to a skinny launch of their own, as in gemm1
+        const int rem = p->E % 128;
+        p->l0_nmain = (p->E > 128 && rem > 0 && rem <= 32) ? p->E - rem : p->E;
+    }
+    std::vector<int> all, bc;
     std::map<int, std::vector<GemmGroup>> fo, wo, dO;
+    std::map<int, std::vector<int>> ko;
     std::map<int, std::vector<ColsumGroup>> co;
     for (int d = 0; d < D; ++d) {
         const AttrDesc& a = p->attrs[d];
+        const int* cnt = rowcnt + d;
+        const int* list = rowidx + (size_t)d * p->Rc;
+        // {A, B, C, bias, aux, csum} + {cnt, aidx, bidx, cidx}
+        auto G = [&](const float* A, const float* B, float* C, const float* bias, const float* aux, float* csum,
+                     const int* aidx = nullptr, const int* bidx = nullptr, const int* cidx = nullptr) {
+            return GemmGroup{A, B, C, bias, aux, csum, cnt, aidx, bidx, cidx};
+        };
         float *a0d = a0 + (size_t)d * 2 * H, *a1d = a1 + (size_t)d * H, *a2d = a2 + (size_t)d * H;
         float *da0d = da0 + (size_t)d * 2 * H, *da1d = da1 + (size_t)d * H, *da2d = da2 + (size_t)d * H;
-        // trunk (decoders.py:60-66)
-        fl1.push_back({a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr});
-        fl2.push_back({a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr});
-        wl2.push_back({da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr});
-        dl2.push_back({da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d, GA(SHIVAE_P_DEC2_B, d)});
-        wl1.push_back({da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr});
-        dl1.push_back({da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d,
-                       p->grads + p->glob[SHIVAE_P_DEC0_B].off + (size_t)d * 2 * H});
+        all.push_back(d);
+        // trunk (decoders.py:60-66).  Layer 0 as a group: the shared input gathered through the attribute's rows.
+        fl0.push_back(G(embc, PA(SHIVAE_P_DEC0_W, d), a0d, PA(SHIVAE_P_DEC0_B, d), nullptr, nullptr, list));
+        // its weight gradient: da0 sits in chunk rows (see dl1), so both operands come through the row list
+        wl0.push_back(G(da0d, embc, GA(SHIVAE_P_DEC0_W, d), nullptr, nullptr, nullptr, list, list));
+        if (p->l0_nmain < p->E)
+            wl0r.push_back(G(da0d, embc + p->l0_nmain, GA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, nullptr, nullptr, nullptr, list, list));
+        fl1.push_back(G(a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr, nullptr));
+        fl2.push_back(G(a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr, nullptr));
+        wl2.push_back(G(da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr, nullptr));
+        dl2.push_back(G(da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d, GA(SHIVAE_P_DEC2_B, d)));
+        wl1.push_back(G(da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr, nullptr));
+        // (cidx: the layer-0 backward is dense over the chunk, so a ragged launch scatters da0 back to chunk rows)
+        dl1.push_back(G(da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d,
+                        p->grads + p->glob[SHIVAE_P_DEC0_B].off + (size_t)d * 2 * H, nullptr, nullptr, list));
         // heads (decoders.py:69-102)
         float* wout = p->params + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
         float* bout = p->params + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
@@ -355,26 +400,32 @@ static int build_tables(shivae_plan* p) {
         if (p->bc_index[d] >= 0) {
             const int jx = p->bc_index[d];
             float *hhj = hh + (size_t)jx * H, *dhhj = dhh + (size_t)jx * H;
-            fh0.push_back({a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr});
-            wh0.push_back({dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr});
-            dh0.push_back({dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d, GA(SHIVAE_P_DEC4_B, d)});
+            bc.push_back(d);
+            fh0.push_back(G(a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr, nullptr));
+            wh0.push_back(G(dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr, nullptr));
+            dh0.push_back(G(dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d, GA(SHIVAE_P_DEC4_B, d)));
             hin = hhj; dhin = dhhj; hmask = hhj; dhbias = GA(SHIVAE_P_HEAD0_B, d);
         }
         // tables are keyed by +nout (input = hh, bin/cat) or -nout (input = a2, real/pos): the two
-        // inputs have different leading dimensions, and a grouped launch shares them
+        // inputs have different leading dimensions, and a grouped launch shares them.
+        // The parameter rows (pbuf) stay in chunk-row order for the likelihood kernel: the head output is stored
+        // through the row list (cidx) and its gradient is read back through it (aidx).
         const int key = p->bc_index[d] >= 0 ? a.nout : -a.nout;
-        fo[key].push_back({hin, wout, pd, bout, nullptr});
-        wo[key].push_back({pd, hin, gwout, nullptr, nullptr});
+        ko[key].push_back(d);
+        fo[key].push_back(G(hin, wout, pd, bout, nullptr, nullptr, nullptr, nullptr, list));
+        wo[key].push_back(G(pd, hin, gwout, nullptr, nullptr, nullptr, list));
         co[key].push_back({pd, gbout});
-        dO[key].push_back({pd, wout, dhin, nullptr, hmask, dhbias});
+        dO[key].push_back(G(pd, wout, dhin, nullptr, hmask, dhbias, list));
     }
-    SV_TRY(make_table(p, fl1, p->f_l1)); SV_TRY(make_table(p, fl2, p->f_l2)); SV_TRY(make_table(p, fh0, p->f_h0));
-    SV_TRY(make_table(p, wl1, p->b_l1_w)); SV_TRY(make_table(p, dl1, p->b_l1_d));
-    SV_TRY(make_table(p, wl2, p->b_l2_w)); SV_TRY(make_table(p, dl2, p->b_l2_d));
-    SV_TRY(make_table(p, wh0, p->b_h0_w)); SV_TRY(make_table(p, dh0, p->b_h0_d));
-    for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first]));
-    for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first]));
-    for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first]));
+    SV_TRY(make_table(p, fl0, p->f_l0, all));
+    SV_TRY(make_table(p, wl0, p->b_l0_w, all)); SV_TRY(make_table(p, wl0r, p->b_l0_wr, all));
+    SV_TRY(make_table(p, fl1, p->f_l1, all)); SV_TRY(make_table(p, fl2, p->f_l2, all)); SV_TRY(make_table(p, fh0, p->f_h0, bc));
+    SV_TRY(make_table(p, wl1, p->b_l1_w, all)); SV_TRY(make_table(p, dl1, p->b_l1_d, all));
+    SV_TRY(make_table(p, wl2, p->b_l2_w, all)); SV_TRY(make_table(p, dl2, p->b_l2_d, all));
+    SV_TRY(make_table(p, wh0, p->b_h0_w, bc)); SV_TRY(make_table(p, dh0, p->b_h0_d, bc));
+    for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first], ko[kv.first]));
+    for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first], ko[kv.first]));
+    for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first], ko[kv.first]));
     for (auto& kv : co) SV_TRY(make_ctable(p, kv.second, p->c_out[kv.first]));
     return SHIVAE_OK;
 }
@@ -436,11 +487,14 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
     GemmGroup g{A, B, C, bias, aux};
     return launch_gemm(d, nullptr, 1, g, s);
 }
+// rag_cnt: pinned host copy of the chunk's row counts while profiling (else null); see prof_ragged
+static const int* g_chunk_cnt_host = nullptr;
 static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epi, const GroupTable& t,
-                 hipStream_t s) {
+                 hipStream_t s, int ragged = 0) {
     if (t.n == 0) return SHIVAE_OK;
-    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned};
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned, ragged};
     if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, t.n);
+    if ((ragged & RAG_CNT) && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, layout == GEMM_TN ? K : M);
     return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
 }
 static int colsum1(int M, int N, int ld, const float* Y, float* out, hipStream_t s) {
@@ -569,18 +623,40 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     float *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
     float *da0 = p->wsf("da0");
     const int ldA0 = p->ldA0, ldA1 = p->ldA1, ldHH = p->ldHH;
+    const bool rag = grad && !keep && p->compact;
+    const int rcnt = rag ? RAG_CNT : 0;
+    int* rowidx = reinterpret_cast<int*>(p->wsf("rowidx"));
+    int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     for (int r0 = 0; r0 < R; r0 += p->Rc) {
         const int rc = std::min(p->Rc, R - r0);
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
-        // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
-        SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
-                     nullptr, 0, EPI_BIAS | EPI_RELU, s));
-        SV_TRY(gemmg(NT, rc, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s));
+        if (rag) {
+            // Mask-aware decoder: attribute d's network only runs on the rows in which d is observed (their
+            // likelihood terms are the only ones in the loss, base_missvae.py:271-285).  Activations of group d
+            // are stored compactly -- row i of its column block = its i-th observed row of the chunk.
+            SV_TRY(launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s));
+            g_chunk_cnt_host = nullptr;
+            if (prof_on()) {
+                int* blk = nullptr;
+                SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&blk), (size_t)D * sizeof(int), hipHostMallocDefault));
+                prof_keep_block(blk);
+                SV_CHECK_HIP(hipMemcpyAsync(blk, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
+                g_chunk_cnt_host = blk;
+            }
+            SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, RAG_CNT | RAG_AIDX));
+        } else {
+            // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
+            SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
+                         nullptr, 0, EPI_BIAS | EPI_RELU, s));
+        }
+        SV_TRY(gemmg(NT, rc, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s, rcnt));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s, rcnt));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s, rcnt));
         for (auto& kv : p->f_out) {
             const int key = kv.first, nout = key < 0 ? -key : key;
-            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s));
+            // (ragged: stored through the row list, so pbuf stays in chunk-row order; the rows of missing entries
+            // keep finite leftovers -- zeros or older parameters -- which the likelihood kernel masks out)
+            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
         }
         if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
                                               hipMemcpyDeviceToDevice, s));
@@ -594,25 +670,37 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         // ---- decoder backward (pbuf now holds d nll / d head outputs) ----
         for (auto& kv : p->b_out_w) {
             const int key = kv.first, nout = key < 0 ? -key : key, ldin = key < 0 ? ldA1 : ldHH;
-            SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s));
+            // (ragged: the gradient rows of the observed entries are read through the row list; the dense column
+            // sums below are unaffected, the gradient is zero where the entry is missing)
+            SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s, rag ? RAG_CNT | RAG_AIDX : 0));
             SV_TRY(colsumg(rc, nout, P, p->c_out[key], s));
             // d(head input) = dP * Wout, gated by the head input's ReLU; its column sums are the bias gradient
             // of the layer that produced the head input (EPI_COLSUM, here and in the trunk below)
-            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s));
+            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s,
+                         rag ? RAG_CNT | RAG_AIDX : 0));
         }
-        SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s));
-        SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s));
-        SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s));
-        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s));
+        SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s, rcnt));
+        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s, rcnt));
+        SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
+        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
+        SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
+        // (ragged: layer 0's backward below is dense over the chunk, so da0 goes back to chunk rows, zero where missing)
+        if (rag) SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
+        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s, rag ? RAG_CNT | RAG_CIDX : 0));
         // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
-        SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
-                     EPI_ATOMIC, s));
+        if (rag) {
+            const int rl = RAG_CNT | RAG_AIDX | RAG_BIDX, nm = p->l0_nmain;
+            SV_TRY(gemmg(TN, 2 * H, nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_w, s, rl));
+            if (nm < E) SV_TRY(gemmg(TN, 2 * H, E - nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_wr, s, rl));
+        } else {
+            SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
+                         EPI_ATOMIC, s));
+        }
         SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
 
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
     }
+    g_chunk_cnt_host = nullptr;
 
     if (grad) {
         // 4. reverse-time scan
@@ -771,7 +859,7 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         build_pack_plan(p, wj, bj, false);
     }
     // decoder row chunk: bytes per row of chunk-local activations
-    const double per_row = 4.0 * ((double)p->D * p->H * 8 + (double)std::max(p->nbc, 1) * p->H * 2 + p->P + 2.0 * p->E4 +
+    const double per_row = 4.0 * ((double)p->D * p->H * 8 + (double)std::max(p->nbc, 1) * p->H * 2 + p->P + p->D + 2.0 * p->E4 +
                                   2.0 * p->Hp + 2.0 * p->Zp);
     int rc = cfg->chunk_rows;
     if (rc <= 0) {
@@ -780,6 +868,10 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         if (rc < p->R) rc = std::max(256, rc / 256 * 256);
     }
     p->Rc = (int)std::min<int64_t>(rc, p->R);
+    {
+        const char* f = getenv("SHIVAE_COMPACT");
+        p->compact = f ? atoi(f) != 0 : 1;
+    }
     build_workspace(p);
     *out = p;
     return SHIVAE_OK;
@@ -976,6 +1068,12 @@ int shivae_profile_stop(double* out, int max_entries) {
     SV_CHECK_HIP(hipDeviceSynchronize());
     double calls[PROF_COUNT] = {0}, ms[PROF_COUNT] = {0}, work[PROF_COUNT] = {0};
     for (auto& r : g_prof) {
+        if (!r.rag_attr || !r.rag_cnt || r.rag_attr->empty() || r.rag_ext <= 0) continue;
+        double live = 0.0;
+        for (int a : *r.rag_attr) live += r.rag_cnt[a];
+        r.work *= live / ((double)r.rag_attr->size() * r.rag_ext);
+    }
+    for (auto& r : g_prof) {
         float t = 0.f;
         if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.id >= 0 && r.id < PROF_COUNT) {
             calls[r.id] += 1; ms[r.id] += t; work[r.id] += r.work;
@@ -997,6 +1095,8 @@ int shivae_profile_stop(double* out, int max_entries) {
     }
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    for (int* b : g_prof_cnt_blocks) (void)hipHostFree(b);
+    g_prof_cnt_blocks.clear();
     int n = 0;
     for (int i = 0; i < PROF_COUNT && n < max_entries; ++i)
         if (calls[i] > 0) { out[4 * n] = i; out[4 * n + 1] = calls[i]; out[4 * n + 2] = ms[i]; out[4 * n + 3] = work[i]; ++n; }

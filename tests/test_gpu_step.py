@@ -1,5 +1,6 @@
 """GPU parity of the full fused step (ShiVAE host API -> C ABI -> HIP kernels) against the golden
 vectors of the reference and against the oracle on larger seeded inputs."""
+import zlib
 import numpy as np
 import pytest
 import torch
@@ -129,7 +130,7 @@ CASES = {
 @pytest.mark.parametrize("name", list(CASES))
 def test_step_matches_oracle_on_seeded_inputs(name):
     tl, T, B, H, Z, K, learn_std, miss, chunk = CASES[name]
-    rng = np.random.default_rng(abs(hash(name)) % 2**31)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))  # (str hashes change per process)
     P = so.init_params(tl, H, Z, K, learn_std, seed=1)
     for k in P:
         if "bias" in k:
