@@ -114,21 +114,49 @@ struct TileLoader {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
+// Row-contiguous (!KC) tiles take the source k-row of each of this lane's pieces from krow[] (DmaRows below): the
+// K range may end inside the tile (rows past it are clamped duplicates; the caller zeroes the A fragment there) and
+// may run through a row list.
+template <bool KC, int ROWS, int NT>
+struct DmaRows {
+    static constexpr int PIECES = ROWS * 32 / 256;               // 1-KiB pieces of the [ROWS x 32] tile
+    static constexpr int PER = (PIECES + NT / 64 - 1) / (NT / 64);  // pieces per wave
+    int krow[PER];
+    // rows of the K-tile at k0, clamped to the last live k-row (the DMA loop waits for all of a wave's loads at its
+    // barrier anyway, so the list may sit behind a uniform branch here)
+    __device__ __forceinline__ void fetch(const int* __restrict__ idx, int k0, int kend, int tid) {
+        if (KC) return;
+        constexpr int LPR = ROWS / 4;  // lanes per k-row
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int pc = wave + j * (NT / 64);
+            krow[j] = max(min(k0 + pc * (64 / LPR) + lane / LPR, kend - 1), 0);
+        }
+        if (idx) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) krow[j] = idx[krow[j]];
+        }
+    }
+};
+
 template <bool KC, int ROWS, int NT>
 __device__ __forceinline__ void dma_tile(const float* __restrict__ X, int ld, int row0, int nrows, int k0, float* stage,
-                                         int tid) {
-    constexpr int PIECES = ROWS * 32 / 256;  // 1-KiB pieces of the [ROWS x 32] tile
+                                         int tid, const DmaRows<KC, ROWS, NT>& rows) {
+    constexpr int PIECES = ROWS * 32 / 256;
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int pc = wave; pc < PIECES; pc += NT / 64) {
+    for (int j = 0; j < DmaRows<KC, ROWS, NT>::PER; ++j) {
+        const int pc = wave + j * (NT / 64);
+        if (pc >= PIECES) break;
         const float* src;
         if (KC) {
             const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
             src = X + (size_t)min(row0 + r, nrows - 1) * ld + k0 + c * 4;
         } else {
-            constexpr int LPR = ROWS / 4;  // lanes per k-row
-            const int kk = pc * (64 / LPR) + lane / LPR, cc = (lane % LPR) * 4;
-            src = X + (size_t)(k0 + kk) * ld + min(row0 + cc, nrows - 4);
+            constexpr int LPR = ROWS / 4;
+            const int cc = (lane % LPR) * 4;
+            src = X + (size_t)rows.krow[j] * ld + min(row0 + cc, nrows - 4);
         }
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(stage + pc * 256), 16, 0, 0);
     }
@@ -151,7 +179,7 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int s, in
 struct GemmParams {
     int M, N, K, lda, ldb, ldc, ldaux, epi, splitk, kchunk, vecA, vecB, vecC, ragged;
     // tile -> workgroup map (see tile_coords): tile counts, super-tile shape (SX*SY*SZ = 64), super-tile counts
-    int ntx, nty, ntz, SX, SY, SZ, cx, cy, nsuper, nlin;
+    int ntx, nty, ntz, SX, SY, SZ, cx, cy, cz, rowslow, nsuper, nlin;
     unsigned long long* stamps;  // diagnostics: 4 s_memtime stamps per workgroup (tools/gemm_stamps.py), else null
     const GemmGroup* groups;
     GemmGroup g0;
@@ -171,7 +199,14 @@ __device__ __forceinline__ bool tile_coords(const GemmParams& p, int lin, int& b
     const int xcd = lin & 7, k = lin >> 3;
     const int s = (k >> 6) * 8 + xcd, within = k & 63;
     if (s >= p.nsuper) return false;
-    const int sx = s % p.cx, sy = (s / p.cx) % p.cy, sz = s / (p.cx * p.cy);
+    int sx, sy, sz;
+    if (p.rowslow) {
+        // ragged rows: row super-tiles slowest, so the dead row tiles of every group (those past its live count)
+        // come last in the launch and all XCDs run out of live work together
+        sz = s % p.cz; sx = (s / p.cz) % p.cx; sy = s / (p.cz * p.cx);
+    } else {
+        sx = s % p.cx; sy = (s / p.cx) % p.cy; sz = s / (p.cx * p.cy);
+    }
     bx = sx * p.SX + within % p.SX;
     by = sy * p.SY + (within / p.SX) % p.SY;
     bz = sz * p.SZ + within / (p.SX * p.SY);
@@ -260,14 +295,20 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         la.init(aidx, g.A, m0, Mrows, kbeg, kend, tid);
         lb.init(bidx, g.B, n0, p.N, kbeg, kend, tid);
     }
-    auto compute = [&](const float* sa, const float* sb) {
+    auto compute = [&](const float* sa, const float* sb, int klim = 32) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float4 a[TM], b[TN];
 #pragma unroll
-            for (int x = 0; x < TM; ++x)
+            for (int x = 0; x < TM; ++x) {
                 a[x] = DMA ? read_frag_swz<A_KC, BM>(sa, (wm * TM + x) * 32 + li, s, lh)
                            : read_frag<A_KC, BM>(sa, (wm * TM + x) * 32 + li, s, lh);
+                if (DMA && !A_KC) {  // k-rows past the live K hold clamped duplicates: they must not count
+                    const int kf = s * 8 + lh * 4;
+                    a[x].x = kf < klim ? a[x].x : 0.f; a[x].y = kf + 1 < klim ? a[x].y : 0.f;
+                    a[x].z = kf + 2 < klim ? a[x].z : 0.f; a[x].w = kf + 3 < klim ? a[x].w : 0.f;
+                }
+            }
 #pragma unroll
             for (int y = 0; y < TN; ++y)
                 b[y] = DMA ? read_frag_swz<B_KC, BN>(sb, (wn * TN + y) * 32 + li, s, lh)
@@ -285,22 +326,35 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     };
     if constexpr (DMA) {
         // two LDS stages filled by LDS-DMA: the next K-tile streams into the other stage while this one is
-        // multiplied; __syncthreads() waits for this wave's DMAs (vmcnt) before the barrier
+        // multiplied; __syncthreads() waits for this wave's DMAs (vmcnt) before the barrier.  The source rows of
+        // the tile after next are fetched one step ahead (ragged launches: through the row lists).
+        DmaRows<A_KC, BM, NT> ra;
+        DmaRows<B_KC, BN, NT> rb;
+        ra.fetch(aidx, kbeg, kend, tid);
+        rb.fetch(bidx, kbeg, kend, tid);
         if (kbeg < kend) {
-            dma_tile<A_KC, BM, NT>(g.A, p.lda, m0, p.M, kbeg, ldsA, tid);
-            dma_tile<B_KC, BN, NT>(g.B, p.ldb, n0, p.N, kbeg, ldsB, tid);
+            dma_tile<A_KC, BM, NT>(g.A, p.lda, m0, Mrows, kbeg, ldsA, tid, ra);
+            dma_tile<B_KC, BN, NT>(g.B, p.ldb, n0, p.N, kbeg, ldsB, tid, rb);
         }
+        ra.fetch(aidx, kbeg + 32, kend, tid);
+        rb.fetch(bidx, kbeg + 32, kend, tid);
         __syncthreads();
         if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
-        int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        int cur = 0, k0 = kbeg;
+        for (; k0 + 32 <= kend; k0 += 32) {  // whole K-tiles: no masking code in this loop
             if (k0 + 32 < kend) {
-                dma_tile<A_KC, BM, NT>(g.A, p.lda, m0, p.M, k0 + 32, ldsA + (cur ^ 1) * STAGE, tid);
-                dma_tile<B_KC, BN, NT>(g.B, p.ldb, n0, p.N, k0 + 32, ldsB + (cur ^ 1) * STAGE, tid);
+                dma_tile<A_KC, BM, NT>(g.A, p.lda, m0, Mrows, k0 + 32, ldsA + (cur ^ 1) * STAGE, tid, ra);
+                dma_tile<B_KC, BN, NT>(g.B, p.ldb, n0, p.N, k0 + 32, ldsB + (cur ^ 1) * STAGE, tid, rb);
+                ra.fetch(aidx, k0 + 64, kend, tid);
+                rb.fetch(bidx, k0 + 64, kend, tid);
             }
             compute(ldsA + cur * STAGE, ldsB + cur * STAGE);
             __syncthreads();
             cur ^= 1;
+        }
+        if (k0 < kend) {  // the K range ends inside this tile
+            compute(ldsA + cur * STAGE, ldsB + cur * STAGE, kend - k0);
+            __syncthreads();
         }
     } else if constexpr (DB) {
         if (kbeg < kend) {
@@ -313,20 +367,19 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         lb.store(ldsB, tid);
         __syncthreads();
         if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
-        int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            const bool more = k0 + 32 < kend;
-            if (more) {
-                la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
-                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
-            }
+        int cur = 0, k0 = kbeg;
+        for (; k0 + 32 < kend; k0 += 32) {  // straight-line body (a branch per K-tile cost 5 % in the DMA loop)
+            la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
             compute(ldsA + cur * STAGE, ldsB + cur * STAGE);
-            if (more) {
-                la.store(ldsA + (cur ^ 1) * STAGE, tid);
-                lb.store(ldsB + (cur ^ 1) * STAGE, tid);
-            }
+            la.store(ldsA + (cur ^ 1) * STAGE, tid);
+            lb.store(ldsB + (cur ^ 1) * STAGE, tid);
             __syncthreads();
             cur ^= 1;
+        }
+        if (k0 < kend) {  // the last K-tile
+            compute(ldsA + cur * STAGE, ldsB + cur * STAGE);
+            __syncthreads();
         }
     } else {
         if (kbeg < kend) {
@@ -524,7 +577,9 @@ static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
         q.SY = pow2_le(q.nty, 64 / q.SX);
         q.SZ = 64 / (q.SX * q.SY);
         q.cx = ceil_div(q.ntx, q.SX); q.cy = ceil_div(q.nty, q.SY);
-        const long long ns = (long long)q.cx * q.cy * ceil_div(q.ntz, q.SZ);
+        q.cz = ceil_div(q.ntz, q.SZ);
+        q.rowslow = (A_KC && (p.ragged & RAG_CNT)) ? 1 : 0;
+        const long long ns = (long long)q.cx * q.cy * q.cz;
         SV_REQUIRE(ns < (1ll << 24), "gemm: too many tiles");
         q.nsuper = (int)ns;
         nblocks = (ns + 7) / 8 * 8 * 64;
@@ -551,11 +606,14 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     // SHIVAE_GEMM_TILE selects the other measured variants (tools/gemm_bench.py).
     static const int mode = [] { const char* f = getenv("SHIVAE_GEMM_TILE"); return f ? atoi(f) : 0; }();
     if (mode == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false>(p, ngroups, stream);  // 8 waves, 1 stage
-    if constexpr (VEC && !B_KC) {
-        // LDS-DMA staging needs whole K-tiles (no zero fill) and at least one 16-B piece per clamped row.
-        // Measured in the training step (B=256, T=100): TN +1.3 %, NN +3 %, NT -1.7 % -> NT keeps the register path.
+    if constexpr (VEC) {
+        // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands
+        // need whole K-tiles, and dense rows (no row lists on this path for them).  Measured in the training step
+        // (B=256, T=100, straight-line K loops): TN 127 -> 135 TFLOP/s, NN +3 %; NT (both operands K-contiguous)
+        // -9 % at K=256 and equal at long K, so NT keeps the register path (SHIVAE_GEMM_DMA bit 2 turns it on).
         static const int dma = [] { const char* f = getenv("SHIVAE_GEMM_DMA"); return f ? atoi(f) : 1; }();
-        if (dma && mode != 3 && !p.ragged && p.K % 32 == 0 && p.M >= 4 && p.N >= 4)
+        const bool want = B_KC ? (dma & 2) != 0 : (dma & 1) != 0;
+        if (want && mode != 3 && p.M >= 4 && p.N >= 4 && (A_KC ? (!p.ragged && p.K % 32 == 0) : true))
             return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, true, true>(p, ngroups, stream);    // 128 x 128, 8 waves, LDS-DMA
     }
     return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, true>(p, ngroups, stream);                  // 128 x 128, 8 waves
@@ -580,7 +638,7 @@ int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, con
     p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux;
     p.epi = d.epi; p.splitk = d.splitk; p.ragged = d.ragged;
     SV_REQUIRE(!d.ragged || groups_dev != nullptr, "gemm: ragged launches take a device group table");
-    SV_REQUIRE(!d.ragged || d.layout != GEMM_TN || d.epi == EPI_ATOMIC, "gemm: a ragged TN launch adds atomically");
+    SV_REQUIRE(!d.ragged || d.layout != GEMM_TN || d.epi == EPI_ATOMIC || d.epi == EPI_ADDC, "gemm: a ragged TN launch accumulates into C");
     SV_REQUIRE(!(d.ragged & RAG_BIDX) || d.layout == GEMM_TN, "gemm: a B row list is for TN");
     SV_REQUIRE(!(d.ragged & RAG_CIDX) || d.layout != GEMM_TN, "gemm: a C row list is for NT / NN");
     p.kchunk = round_up(ceil_div(d.K > 0 ? d.K : 1, d.splitk), 32);

@@ -455,6 +455,11 @@ static int splitk_fill(int M, int N, int K, int min_chunk) {
     return best;
 }
 
+static bool use_addc() {
+    static const bool on = [] { const char* f = getenv("SHIVAE_GEMM_ADDC"); return !f || atoi(f) != 0; }();
+    return on;
+}
+
 static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                  const float* bias, const float* aux, int ldaux, int epi, hipStream_t s) {
     // A few columns past a multiple of 128 (E = 2H+K = 528 at H=256, K=16) would cost a whole extra
@@ -474,7 +479,11 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
                      aux ? aux + Nm : nullptr, ldaux, epi, s);
     }
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, 0, 0};
-    if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, 1);
+    if (epi == EPI_ATOMIC) {
+        d.splitk = splitk_for(M, N, K, 1);
+        // one workgroup per output tile: accumulate with a plain 16-B read-modify-write instead of atomics
+        if (d.splitk == 1 && use_addc()) d.epi = EPI_ADDC;
+    }
     if (epi == 0 && K >= 8192) {
         // long K but too few output tiles to fill 256 CUs x 4 blocks: zero C, split K, accumulate atomically
         const int sk = splitk_fill(M, N, K, 4096);
@@ -493,7 +502,10 @@ static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int
                  hipStream_t s, int ragged = 0) {
     if (t.n == 0) return SHIVAE_OK;
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned, ragged};
-    if (epi == EPI_ATOMIC) d.splitk = splitk_for(M, N, K, t.n);
+    if (epi == EPI_ATOMIC) {
+        d.splitk = splitk_for(M, N, K, t.n);
+        if (d.splitk == 1 && use_addc()) d.epi = EPI_ADDC;
+    }
     if ((ragged & RAG_CNT) && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, layout == GEMM_TN ? K : M);
     return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
 }
