@@ -110,6 +110,10 @@ struct AttrDesc;
 // chunk in which the attribute is observed, cnt[d] = how many (base_missvae.py:271-274 picks the mask column).
 int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, int* idx,
                          int ld_idx, int* cnt, hipStream_t stream);
+// Zero Y[row][d*blk .. (d+1)*blk) for every (row, attribute d) that is missing (what a ragged launch that stores
+// through a row list leaves untouched).
+int launch_zero_missing_blocks(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, float* Y,
+                               int ldy, int blk, hipStream_t stream);
 
 
 // ---------------------------------------------------------------- loss kernels (loss.hip)

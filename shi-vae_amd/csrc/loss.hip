@@ -699,4 +699,35 @@ int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, 
     return SHIVAE_OK;
 }
 
+// Zero the column blocks of the missing (row, attribute) pairs of Y[rows][D*blk] (float4 stores; blk % 4 == 0,
+// 16-B aligned rows): the rows a ragged launch with a C row list does not store.  One workgroup per row: the first
+// D threads look up their attribute's mask byte, the missing ones are listed in LDS, then all threads clear them.
+__global__ __launch_bounds__(256) void zero_missing_blocks_kernel(const AttrDesc* __restrict__ attrs, int D,
+                                                                  const uint8_t* __restrict__ mask, int ldm, float* __restrict__ Y,
+                                                                  int ldy, int blk) {
+    extern __shared__ int zm_list[];  // [D] missing attributes of this row, then the count
+    __shared__ int zm_n;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) zm_n = 0;
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+        const AttrDesc a = attrs[d];
+        if (mask[(size_t)row * ldm + a.xoff + a.dim - 1] != 0) zm_list[atomicAdd(&zm_n, 1)] = d;
+    }
+    __syncthreads();
+    const int n = zm_n, per = blk / 4;
+    float4* yrow = reinterpret_cast<float4*>(Y + (size_t)row * ldy);
+    for (int i = tid; i < n * per; i += 256) yrow[(size_t)zm_list[i / per] * per + i % per] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_zero_missing_blocks(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, float* Y,
+                               int ldy, int blk, hipStream_t stream) {
+    if (D <= 0 || rows <= 0) return SHIVAE_OK;
+    SV_REQUIRE(blk % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0, "zero_missing_blocks: 16-B pieces");
+    hipLaunchKernelGGL(zero_missing_blocks_kernel, dim3(rows), dim3(256), (size_t)D * sizeof(int), stream, attrs_dev, D,
+                       mask, ldm, Y, ldy, blk);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
 }  // namespace shivae

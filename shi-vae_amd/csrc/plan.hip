@@ -696,8 +696,14 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
         SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
         SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
-        // (ragged: layer 0's backward below is dense over the chunk, so da0 goes back to chunk rows, zero where missing)
-        if (rag) SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
+        // (ragged: layer 0's backward below is dense over the chunk, so da0 goes back to chunk rows; the
+        // missing (row, attribute) blocks, which the row list skips, are cleared first)
+        if (rag) {
+            if ((2 * H) % 4 == 0 && ldA0 % 4 == 0)
+                SV_TRY(launch_zero_missing_blocks(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, da0, ldA0, 2 * H, s));
+            else
+                SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
+        }
         SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s, rag ? RAG_CNT | RAG_CIDX : 0));
         // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
         if (rag) {
