@@ -260,7 +260,10 @@ int launch_heter_nll(const AttrDesc* attrs_dev, int D, int learn_std, const floa
         // amortise the descriptor table, short enough rounds that a mis-estimated residency costs a few
         // per cent.  (One-wave workgroups reading descriptors from L2 measured 15 % slower.)
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, (160 * 1024) / lds));
-        const int grid = std::min(ceil_div(rows, 4), 256 * per_cu * 4);
+        // (whole rows per wave: every wave of the strided loop gets the same count, so a launch of a few tens of
+        // thousands of rows has no half-empty last round)
+        const int rpw = ceil_div(rows, 4 * 256 * per_cu * 4);
+        const int grid = ceil_div(rows, 4 * rpw);
         static const bool exact = getenv("SHIVAE_NLL_EXACT") != nullptr;
         if (exact) hipLaunchKernelGGL(heter_nll_stream_kernel<false>, dim3(grid), dim3(256), lds, stream, q);
         else hipLaunchKernelGGL(heter_nll_stream_kernel<true>, dim3(grid), dim3(256), lds, stream, q);

@@ -24,7 +24,7 @@ def timeit(fn, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-for rows in (16640, 1048576):
+for rows in (16640, 36600, 1048576):
     x = torch.randn(rows, X, device="cuda")
     mask = (torch.rand(rows, X, device="cuda") < miss).to(torch.uint8)
     Pt = torch.randn(rows, P, device="cuda")
