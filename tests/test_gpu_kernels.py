@@ -27,7 +27,10 @@ def _gemm(layout, A, B, C0, bias=None, aux=None, epi=0, splitk=1, M=None, N_=Non
 
 
 SHAPES = [(1, 1, 1), (5, 3, 7), (33, 65, 31), (128, 128, 32), (130, 20, 23), (257, 129, 100), (64, 300, 36),
-          (1000, 17, 260), (40, 513, 64), (300, 2, 256), (2, 300, 256)]
+          (1000, 17, 260), (40, 513, 64), (300, 2, 256), (2, 300, 256),
+          # 16-B aligned 128x128-tile cases: LDS-DMA staging (TN / NN) with a K range that ends inside a K-tile,
+          # a K shorter than one tile, whole tiles only
+          (132, 260, 100), (128, 132, 4), (200, 136, 333), (256, 256, 96)]
 
 
 @pytest.mark.parametrize("M,Nn,K", SHAPES)
