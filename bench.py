@@ -180,7 +180,8 @@ def main():
                                   "h_dim=%d, z_dim=%d, K=%d, %d%% missing; fwd+bwd+allreduce+clip+Adam"
                                   % (a.config, B, T, len(tl), nr, npos, nb, len(cats), H, Z, K, int(miss * 100)),
                       "global_batch": B, "seq_len": T, "parallelism": "dp%d" % world,
-                      "micro_batch": model.micro_batch(T, Bl), "params": int(sum(p.numel() for p in model.parameters()))},
+                      "micro_batch": model.micro_batch(T, Bl), "params": int(sum(p.numel() for p in model.parameters())),
+                      "missing_frac": round(float(mask.float().mean()), 4)},
            "n_elbo": float(lv), "roofline": roof, "roofline_other_kernels": others}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.config, tl, H, Z, K)

@@ -2,6 +2,8 @@
 src/hmm_dataset/heterHMMdataset.py: K-state Markov chain :76-94, per-state Gaussian / softplus-Gaussian /
 Bernoulli / dominant-class categorical emissions :127-249, burst missing masks :292-363), already
 scaled (standardised real, log1p-standardised pos), one-hot expanded and zero-filled, time-major."""
+import math
+
 import torch
 
 
@@ -35,8 +37,10 @@ def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda"
                 other = torch.randint(0, dim, (T, b), generator=g, device=device)
                 keep = torch.rand(T, b, generator=g, device=device) < 0.9
                 cols.append(torch.nn.functional.one_hot(torch.where(keep, dom, other), dim).float())
-            # bursts of length U(3,10) until ~round(T*miss) steps are masked
-            nb = max(1, int(round(T * miss / 6.5)))
+            # bursts of length U(3,10) until ~round(T*miss) steps are masked (heterHMMdataset.py:292-363 draws bursts
+            # until that count is reached; here the number of bursts is fixed so that, overlaps included, the
+            # expected masked fraction is `miss`: 1 - exp(-nb * 6.5 / T) = miss)
+            nb = max(1, int(round(-math.log(max(1.0 - miss, 1e-6)) * T / 6.5)))
             start = torch.randint(0, T, (nb, b), generator=g, device=device)
             length = torch.randint(3, 11, (nb, b), generator=g, device=device)
             diff = torch.zeros(T + 1, b, device=device)
