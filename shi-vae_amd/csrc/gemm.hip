@@ -7,7 +7,12 @@
 //
 // Tile: (WM*TM*32) x (WN*TN*32) x 32 per workgroup of WM*WN waves (64 lanes each); each wave owns
 // TM x TN accumulators of 32x32.  Operands are staged global -> registers -> LDS with the next
-// K-tile's global loads in flight during the MFMAs of the current one.
+// K-tile's global loads in flight during the MFMAs of the current one; the 128x128 TN / NN tile stages
+// by LDS-DMA instead (global_load_lds_dwordx4, no register round trip).  The K loops are straight-line:
+// the last K-tile is peeled rather than guarded inside the loop (a branch per K-tile cost 5 %).
+//
+// Ragged groups (the mask-aware decoder, GemmDesc::ragged): a group's live extent can be a device-side
+// count and its rows can go through index lists -- see GemmGroup in common.h and the kernel head below.
 //
 // LDS images and bank behaviour (MI355X_MICROARCH.md, LDS):
 //   K-contiguous operand  : [rows][32+4] floats.  A lane reads the 4 consecutive k it needs for
