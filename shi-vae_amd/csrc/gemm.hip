@@ -34,6 +34,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
+// Operand pointers come out of the group table, so the compiler only knows them as generic pointers and would
+// emit flat_load: flat operations count on BOTH vmcnt and lgkmcnt, and the first `s_waitcnt lgkmcnt(0)` for an
+// LDS fragment read then also waits for the global loads of the next K-tile issued just before it -- the
+// prefetch stops overlapping the MFMAs.  Loads through these global-address-space views are global_load.
+typedef const __attribute__((address_space(1))) float* gbl_f32_ptr;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gbl_f32x4_ptr;
+typedef const __attribute__((address_space(1))) int* gbl_i32_ptr;
+
 template <bool KC, int ROWS, int NT, bool VEC>
 struct TileLoader {
     // KC : global X[row*ld + k], tile rows = ROWS along the M/N extent, 32 along K
@@ -52,7 +61,7 @@ struct TileLoader {
     // (the list is read unconditionally -- without a list, a dummy word of the operand itself -- and selected
     // afterwards: a branch around the load would put a full vmcnt(0) wait into the K loop)
     __device__ __forceinline__ static int pick(const int* __restrict__ idx, const float* __restrict__ X, int i, int lim) {
-        const int* q = idx ? idx : reinterpret_cast<const int*>(X);
+        const gbl_i32_ptr q = idx ? (gbl_i32_ptr)idx : (gbl_i32_ptr)X;
         const int t = q[(idx && i < lim) ? i : 0];
         return idx ? t : i;
     }
@@ -76,16 +85,17 @@ struct TileLoader {
             else    { k = f / (ROWS / 4); r = (f % (ROWS / 4)) * 4; }
             const int gr = row0 + r, gk = k0 + k;
             const size_t off = KC ? (size_t)src[i] * ld + gk : (size_t)src[i] * ld + gr;
+            const gbl_f32_ptr Xg = (gbl_f32_ptr)X;
             if (VEC) {  // contiguous extent is a multiple of 4: a float4 is all-valid or all-invalid
                 const bool ok = gr < nrows && gk < kend;
-                const float4 x = *reinterpret_cast<const float4*>(X + (ok ? off : 0));
-                v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4 x = *(gbl_f32x4_ptr)(Xg + (ok ? off : 0));
+                v[i] = ok ? make_float4(x.x, x.y, x.z, x.w) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 float e[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const bool ok = KC ? (gr < nrows && gk + c < kend) : (gk < kend && gr + c < nrows);
-                    const float t = X[ok ? off + c : 0];
+                    const float t = Xg[ok ? off + c : 0];
                     e[c] = ok ? t : 0.f;
                 }
                 v[i] = make_float4(e[0], e[1], e[2], e[3]);
