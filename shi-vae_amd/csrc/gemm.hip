@@ -42,6 +42,22 @@ typedef const __attribute__((address_space(1))) float* gbl_f32_ptr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gbl_f32x4_ptr;
 typedef const __attribute__((address_space(1))) int* gbl_i32_ptr;
+// (the same for the epilogue: a flat_store also counts on lgkmcnt, so the LDS read of the next piece of the
+// staged tile would wait for the previous piece's stores to complete)
+__device__ __forceinline__ float4 gload4(const float* p) {
+    const f32x4 t = *(gbl_f32x4_ptr)p;
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float gload(const float* p) { return *(gbl_f32_ptr)p; }
+__device__ __forceinline__ void gstore4(float* p, float a, float b, float c, float d) {
+    f32x4 t;
+    t.x = a; t.y = b; t.z = c; t.w = d;
+    *(__attribute__((address_space(1))) f32x4*)p = t;
+}
+__device__ __forceinline__ void gstore(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
+__device__ __forceinline__ void gatomic_add(float* p, float v) {
+    __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool KC, int ROWS, int NT, bool VEC>
 struct TileLoader {
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
             float bias4[4] = {0.f, 0.f, 0.f, 0.f};
             if ((epi & EPI_BIAS) && colok) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) bias4[c] = g.bias[col + c];
+                for (int c = 0; c < 4; ++c) bias4[c] = gload(g.bias + col + c);
             }
 #pragma unroll
             for (int pi = 0; pi < BANDS / G; ++pi) {
@@ -448,8 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                     for (int i = 0; i < PER; ++i) {
                         const int lr = (tid + i * NT) / (BN / 4);
                         const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
-                        ax[i] = *reinterpret_cast<const float4*>(
-                            g.aux + ((colok && row < Mrows) ? (size_t)row * p.ldaux + col : 0));
+                        ax[i] = gload4(g.aux + ((colok && row < Mrows) ? (size_t)row * p.ldaux + col : 0));
                     }
                 }
 #pragma unroll
@@ -475,12 +490,12 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                         const int lr = (tid + (i0 + i) * NT) / (BN / 4);
                         const int row = m0 + (pi * G + (lr >> 5)) * 32 + (lr & 31);
                         ok[i] = colok && row < Mrows;
-                        const int crow = cidx ? cidx[ok[i] ? row : 0] : row;
+                        const int crow = cidx ? ((gbl_i32_ptr)cidx)[ok[i] ? row : 0] : row;
                         off[i] = ok[i] ? (size_t)crow * p.ldc + col : 0;
                         v[i] = *reinterpret_cast<const float4*>(lds + lr * LDE + c4 * 4);
-                        if (epi & EPI_ADDC) cold[i] = *reinterpret_cast<const float4*>(g.C + off[i]);
+                        if (epi & EPI_ADDC) cold[i] = gload4(g.C + off[i]);
                         if (!PF && (epi & EPI_MASK))
-                            ax[i0 + i] = *reinterpret_cast<const float4*>(g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
+                            ax[i0 + i] = gload4(g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
                     }
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                         float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
                         if (epi & EPI_ATOMIC) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) atomicAdd(cp + c, e[c]);
+                            for (int c = 0; c < 4; ++c) gatomic_add(cp + c, e[c]);
                             continue;
                         }
 #pragma unroll
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                             e[0] = a4.x > 0.f ? e[0] : 0.f; e[1] = a4.y > 0.f ? e[1] : 0.f;
                             e[2] = a4.z > 0.f ? e[2] : 0.f; e[3] = a4.w > 0.f ? e[3] : 0.f;
                         }
-                        *reinterpret_cast<float4*>(cp) = make_float4(e[0], e[1], e[2], e[3]);
+                        gstore4(cp, e[0], e[1], e[2], e[3]);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) cs4[c] += e[c];
                     }
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                     float t = 0.f;
 #pragma unroll
                     for (int k = 0; k < NT / (BN / 4); ++k) t += lds[k * BN + tid];
-                    atomicAdd(g.csum + n0 + tid, t);
+                    gatomic_add(g.csum + n0 + tid, t);
                 }
             }
             if (p.stamps && tid == 0) {
@@ -543,27 +558,27 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         for (int y = 0; y < TN; ++y) {
             const int col = n0 + (wn * TN + y) * 32 + li;
             if (col >= p.N) continue;
-            const float bias = (epi & EPI_BIAS) ? g.bias[col] : 0.f;
+            const float bias = (epi & EPI_BIAS) ? gload(g.bias + col) : 0.f;
             float cs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= Mrows) continue;
-                float* cp = g.C + (size_t)(cidx ? cidx[row] : row) * p.ldc + col;
+                float* cp = g.C + (size_t)(cidx ? ((gbl_i32_ptr)cidx)[row] : row) * p.ldc + col;
                 float v = acc[x][y][r];
                 if (epi & EPI_ATOMIC) {
-                    atomicAdd(cp, v);
+                    gatomic_add(cp, v);
                     continue;
                 }
                 v += bias;
-                if (epi & EPI_ADDC) v += *cp;
+                if (epi & EPI_ADDC) v += gload(cp);
                 if (epi & EPI_RELU) v = fmaxf(v, 0.f);
                 if (epi & EPI_SOFTPLUS) v = softplus_f(v);
-                if (epi & EPI_MASK) v = g.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
-                *cp = v;
+                if (epi & EPI_MASK) v = gload(g.aux + (size_t)row * p.ldaux + col) > 0.f ? v : 0.f;
+                gstore(cp, v);
                 cs += v;
             }
-            if (epi & EPI_COLSUM) atomicAdd(g.csum + col, cs);
+            if (epi & EPI_COLSUM) gatomic_add(g.csum + col, cs);
         }
 }
 
