@@ -166,6 +166,8 @@ struct DmaRows {
         }
         if (idx) {
 #pragma unroll
+            // (a generic pointer on purpose: the flat_load counts on lgkmcnt and leaves the vmcnt queue to the
+            // DMAs; through the global address space this loop measured 6 % slower)
             for (int j = 0; j < PER; ++j) krow[j] = idx[krow[j]];
         }
     }
@@ -179,7 +181,9 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ X, int ld, in
 #pragma unroll
     for (int j = 0; j < DmaRows<KC, ROWS, NT>::PER; ++j) {
         const int pc = wave + j * (NT / 64);
-        if (pc >= PIECES) break;
+        if constexpr (PIECES % (NT / 64) != 0) {  // (otherwise every wave has exactly PER pieces: no branch in the K loop)
+            if (pc >= PIECES) break;
+        }
         const float* src;
         if (KC) {
             const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
