@@ -484,6 +484,14 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                     }
                 }
                 __syncthreads();
+                if (PF && (epi & EPI_MASK)) {
+                    // Keep the gate values as raw registers until here: without this the compiler turns them into
+                    // lane masks right after the loads, i.e. waits for the loads BEFORE the staging above and the
+                    // barrier, and the memory round trip they were meant to hide is back on the critical path.
+#pragma unroll
+                    for (int i = 0; i < PER; ++i)
+                        asm volatile("" : "+v"(ax[i].x), "+v"(ax[i].y), "+v"(ax[i].z), "+v"(ax[i].w));
+                }
 #pragma unroll
                 for (int i0 = 0; i0 < PER; i0 += CH) {
                     float4 v[CH], cold[CH];
