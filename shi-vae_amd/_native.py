@@ -165,7 +165,7 @@ class Plan:
         return int(lib().shivae_output_width(self.h, which))
 
 
-_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128", "128x64"]
+_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128", "128x256"]
 _LAYOUTS = ["NT", "NN", "TN"]
 
 

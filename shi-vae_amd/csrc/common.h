@@ -34,7 +34,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
-// ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x64 = the short-K tile)
+// ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x256)
 enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_COUNT = 22 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);

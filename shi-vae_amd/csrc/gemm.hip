@@ -648,14 +648,6 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     // SHIVAE_GEMM_TILE selects the other measured variants (tools/gemm_bench.py).
     static const int mode = [] { const char* f = getenv("SHIVAE_GEMM_TILE"); return f ? atoi(f) : 0; }();
     if (mode == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false>(p, ngroups, stream);  // 8 waves, 1 stage
-    if constexpr (VEC && A_KC && B_KC) {
-        // Short K (the H x H trunk layers at H = 256): a tile lives mostly in its prologue and epilogue, which only
-        // other workgroups on the CU can cover.  128 x 64 tiles on 4 waves with one LDS stage (27 KB) put four
-        // workgroups on a CU instead of two: +3 ... +5 % at K = 256 (and -2 ... -17 % from K = 512 up, hence the bound).
-        static const int short_k = [] { const char* f = getenv("SHIVAE_GEMM_SHORTK"); return f ? atoi(f) : 256; }();
-        if (mode == 0 && p.K <= short_k && p.K >= 64)
-            return launch_cfg<A_KC, B_KC, VEC, 4, 1, 1, 2, 4, false>(p, ngroups, stream);              // 128 x 64, 4 waves
-    }
     if constexpr (VEC) {
         // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands
         // need whole K-tiles, and dense rows (no row lists on this path for them).  Measured in the training step
