@@ -573,4 +573,9 @@ class ShiVAE(nn.Module):
         batch shard with inv_batch = 1/B_global, so the sum IS the global-batch gradient."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # The gradient buffer is complete once the step's kernels have run: wait for them on the host before
+            # handing it to the collective (one wait per multi-second step).  RCCL would order itself behind the
+            # stream anyway; the gloo path used in CPU/1-GPU rehearsals was seen to hang without it.
+            if self._gflat.is_cuda:
+                torch.cuda.current_stream().synchronize()
             dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)
