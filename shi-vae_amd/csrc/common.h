@@ -160,6 +160,7 @@ struct ScanArgs {
     int T, B, H, Z, K, Hp, Zp, Kp, Ep;
     float temp;
     const float* wpack;
+    int wlds_floats;  // size of wpack if the kernel may keep all of it in LDS (small models), else 0
     ScanWOff w;
     const float *xs_pre, *ex_pre, *u, *eps;
     float *emb, *as_, *e1, *e2, *logits, *probs, *mu, *sd, *z, *gates, *cnew, *h_last;

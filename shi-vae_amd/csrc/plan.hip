@@ -527,6 +527,7 @@ static ScanArgs scan_args(shivae_plan* p, const float* u, const float* eps, floa
     a.T = p->T; a.B = p->B; a.H = p->H; a.Z = p->Z; a.K = p->K;
     a.Hp = p->Hp; a.Zp = p->Zp; a.Kp = p->Kp; a.Ep = p->Ep; a.temp = temp;
     a.wpack = p->wsf("wpack"); a.w = p->woff;
+    a.wlds_floats = (int)p->wpack_floats;
     a.xs_pre = p->wsf("xs_pre"); a.ex_pre = p->wsf("ex_pre"); a.u = u; a.eps = eps;
     a.emb = p->wsf("emb"); a.as_ = p->wsf("as"); a.e1 = p->wsf("e1"); a.e2 = p->wsf("e2");
     a.logits = p->wsf("logits"); a.probs = p->wsf("probs"); a.mu = p->wsf("mu"); a.sd = p->wsf("sd");

@@ -94,7 +94,9 @@ __device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0
 // is issued in the first two phases, where it overlaps the one-wave logits/Gumbel-softmax stage; the
 // operands that do not depend on the recurrence (xs_pre, ex_pre, eps, u) are requested at the top of
 // the step so their HBM latency is off the chain.  A wave owns hidden tiles ht = wid + s*NW, s < MAXS.
-template <int MAXS, int NTH>
+// WLDS: the packed weights of a small model fit in LDS next to the activations; they are copied there once and
+// every step's operand fetch is an LDS read instead of an L2 round trip on the serial chain.
+template <int MAXS, int NTH, bool WLDS>
 __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
@@ -110,7 +112,11 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
     float* sbuf = bufB + Hp * 16;
     float* lgbuf = sbuf + Kp * 16;
     float* zbuf = lgbuf + Kp * 16;
-    const float* Wb = a.wpack;
+    float* wl = zbuf + Zp * 16;
+    if (WLDS)
+        for (int i = tid; i < a.wlds_floats / 4; i += blockDim.x)
+            reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(a.wpack)[i];
+    const float* Wb = WLDS ? wl : a.wpack;
     const f32x4 zero4 = {0, 0, 0, 0};
 
     for (int i = tid; i < Hp * 16; i += blockDim.x) hb0[i] = 0.f;  // shivae.py:93 h0 = 0
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------- backward
-template <int MAXS, int NTH>
+template <int MAXS, int NTH, bool WLDS>
 __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
@@ -545,7 +551,11 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
     float* dsdb = dmub + Zp * 16;
     float* dsb = dsdb + Zp * 16;
     float* dlgb = dsb + Kp * 16;
-    const float* Wb = a.wpack;
+    float* wl = dlgb + Kp * 16;
+    if (WLDS)
+        for (int i = tid; i < a.wlds_floats / 4; i += blockDim.x)
+            reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(a.wpack)[i];
+    const float* Wb = WLDS ? wl : a.wpack;
     const f32x4 zero4 = {0, 0, 0, 0};
 
     for (int i = tid; i < Hp * 16; i += blockDim.x) dhb[i] = 0.f;
@@ -787,11 +797,11 @@ static int scan_geometry(const ScanArgs& a, int& nw, int& maxs) {
 size_t scan_fwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (4 * a.Hp + 2 * a.Kp + a.Zp); }
 size_t scan_bwd_lds_bytes(const ScanArgs& a) { return sizeof(float) * 16 * (7 * a.Hp + 2 * a.Kp + 2 * a.Zp); }
 
-template <int MAXS, int NTH>
+template <int MAXS, int NTH, bool WLDS = false>
 static int launch_scan_t(const ScanArgs& a, bool bwd, int nw, hipStream_t stream) {
-    const size_t lds = bwd ? scan_bwd_lds_bytes(a) : scan_fwd_lds_bytes(a);
+    const size_t lds = (bwd ? scan_bwd_lds_bytes(a) : scan_fwd_lds_bytes(a)) + (WLDS ? sizeof(float) * a.wlds_floats : 0);
     SV_REQUIRE(lds <= 160 * 1024, "scan: needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = bwd ? scan_bwd_kernel<MAXS, NTH> : scan_fwd_kernel<MAXS, NTH>;
+    auto kern = bwd ? scan_bwd_kernel<MAXS, NTH, WLDS> : scan_fwd_kernel<MAXS, NTH, WLDS>;
     if (lds > 64 * 1024)
         SV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -822,6 +832,13 @@ int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream) {
         }
         set_error("scan: unsupported geometry nw=%d maxs=%d", nw, maxs);
         return SHIVAE_ERR_INVALID;
+    }
+    if (maxs == 1) {
+        // small model (h_dim <= 64): keep the packed weights in LDS when they fit beside the activations
+        static const bool wlds = [] { const char* f = getenv("SHIVAE_SCAN_WLDS"); return !f || atoi(f) != 0; }();
+        const size_t tot = (bwd ? scan_bwd_lds_bytes(a) : scan_fwd_lds_bytes(a)) + sizeof(float) * a.wlds_floats;
+        if (wlds && a.wlds_floats > 0 && a.wlds_floats % 4 == 0 && tot <= 96 * 1024)
+            return launch_scan_t<1, 256, true>(a, bwd, nw, stream);
     }
     switch (maxs) {
         case 1: return launch_scan_t<1, 256>(a, bwd, nw, stream);
