@@ -4,17 +4,28 @@
   python bench.py --gpus N --steps K --warmup W [--config cfg3]
 
 One process per GPU (torch.distributed over RCCL when N > 1, launched by torch.distributed.run);
-rank 0 prints ONE JSON line.  Metric: train sequence-timesteps/s = B_global*T / step time.
+rank 0 prints ONE JSON line.  Metric: train sequence-timesteps/s = B_global*T / median step time.
 Default workload = BASELINE.json configs[2] ("cfg3"): synthetic heterogeneous HMM, global batch 8192,
 T=1000, D=256 mixed types (64 real/64 pos/64 bin/64 cat, C=4), h_dim=256, z_dim=64, K=16, 30 % missing;
-N GPUs split the SAME global batch (strong scaling, configs[3])."""
+N GPUs shard the SAME global batch by sequence (strong scaling, configs[3]): rank r generates exactly rows
+[r*B/N, (r+1)*B/N) of the batch a single process would generate.
+
+Wall-clock budget: one full-size fp32 step is tens of seconds, so the requested warm-up / step counts are
+clamped to what fits SHIVAE_BENCH_BUDGET_S (default 480 s, counted from process start; at least 2 warm-up and
+3 timed steps).  The JSON line reports the counts that actually ran (`steps`, `warmup`) next to the requested
+ones.  Order: set-up -> bounded CPU baseline (rank 0, N=1) -> cold warm-up step -> one warm step under the
+library's per-launch HIP events (the roofline figures; never inside the timed region) -> remaining warm-ups ->
+timed steps (per-step host clock after a device sync; max over ranks; the median is reported)."""
 import argparse
 import json
+import math
 import os
 import sys
 import time
 
-import torch
+T_PROC0 = time.perf_counter()
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,7 +44,30 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfgname, types_list, H, Z, K):
+def host_cores():
+    """(physical cores of the host, CPUs this process may run on)."""
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    return len(phys) or (os.cpu_count() or 1), aff
+
+
+def cpu_baseline(cfgname, types_list, H, Z, K, seconds=14.0):
     """The numpy oracle (a port of the reference algorithm) timed on the host cores on a bounded sample."""
     import numpy as np
     from oracle import shivae_oracle as so
@@ -49,36 +83,59 @@ def cpu_baseline(cfgname, types_list, H, Z, K):
     m = {k: np.zeros_like(v) for k, v in P.items()}
     v = {k: np.zeros_like(v) for k, v in P.items()}
     times = []
-    t_end = time.time() + 25
-    for step in range(1, 4):
+    t_end = time.time() + seconds
+    for step in range(1, 9):
         t0 = time.time()
         om = so.OracleShiVAE(P, types_list, H, Z, K, True, dtype=np.float32)
         om.forward(x, mask, u, eps, 1.0, 3.0)
         G = om.backward()
         so.clip_adam_step(P, G, m, v, step)
         times.append(time.time() - t0)
-        if time.time() > t_end:
+        if step >= 3 and time.time() > t_end:
             break
     dt = sorted(times)[len(times) // 2]
+    threads = None
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
-    return {"value": Bc * Tc / dt, "unit": "sequence-timesteps/s", "cores": cores, "kind": "port",
+        pass
+    phys, aff = host_cores()
+    if threads is None:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    used = min(threads, aff)
+    return {"value": Bc * Tc / dt, "unit": "sequence-timesteps/s", "cores": used, "kind": "port",
+            "host_physical_cores": phys, "cpus_allowed": aff,
+            "threads": "BLAS pool of %d threads (OMP_NUM_THREADS=%s)" % (threads, os.environ.get("OMP_NUM_THREADS", "unset")),
             "sample": "numpy oracle (fp32), %s model, B=%d T=%d, fwd+bwd+clip+Adam, median of %d steps"
                       % (cfgname, Bc, Tc, len(times))}
+
+
+def pmc_traffic(cfgname, B, T, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this workload
+    (profiles/, collected per MI355X_MICROARCH.md), or None when no pass of this configuration is on file."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tab = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    for e in tab.get("entries", []):
+        if e.get("config") == cfgname and e.get("global_batch") == B and e.get("seq_len") == T and e.get("kernel") == kernel:
+            return e.get("hbm_bytes_per_launch"), e.get("source")
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3", choices=list(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the global batch (parity/debug runs)")
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("SHIVAE_BENCH_BUDGET_S", "480")),
+                    help="wall-clock seconds for the whole process; counts are clamped to fit")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,14 +160,26 @@ def main():
     T = a.T or T
     assert B % world == 0, "global batch must divide over the ranks"
     Bl = B // world
+
+    def say(msg):
+        if rank == 0:
+            print("[bench %6.1f s] %s" % (time.perf_counter() - T_PROC0, msg), file=sys.stderr, flush=True)
+
     tl = shivae_amd.utils.make_types_list(nr, npos, nb, cats)
     torch.manual_seed(0)  # same replica on every rank (reference init scheme, seed 0)
     model = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
     model.check_nan = False
     model.train()
     opt = shivae_amd.FusedClipAdam(model, lr=5e-3, clip=0.5)
-    x, mask = synth_batch(tl, T, Bl, miss=miss, seed=1234 + rank, device="cuda")
+    # one global batch (seed 1234), sharded by sequence: blocks of `blk` sequences have their own generator streams
+    blk = max(1, math.gcd(512, B // 16)) if B % 16 == 0 else B
+    assert (rank * Bl) % blk == 0, "shard of %d sequences does not start on a block of %d" % (Bl, blk)
+    x, mask = synth_batch(tl, T, Bl, miss=miss, seed=1234, device="cuda", chunk=blk, seq0=rank * Bl)
     torch.manual_seed(100 + rank)  # per-rank noise stream (device generator)
+    micro = model.micro_batches(T, Bl)
+    torch.cuda.synchronize()
+    say("set-up done: %s B=%d (local %d, micro-batches %s) T=%d, %d parameters"
+        % (a.config, B, Bl, micro, T, sum(p.numel() for p in model.parameters())))
 
     trace = os.environ.get("SHIVAE_BENCH_TRACE") is not None
 
@@ -139,45 +208,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if rank == 0:  # a full-size step takes about a minute: keep stderr alive for watchdogs (no GPU work here)
+    if rank == 0:  # a full-size step takes most of a minute: keep stderr alive for watchdogs (no GPU work here)
         import threading
-        t_start = time.perf_counter()
+
         def heartbeat():
             while True:
                 time.sleep(30)
-                print("[bench] running, %.0f s elapsed" % (time.perf_counter() - t_start), file=sys.stderr, flush=True)
+                say("running")
         threading.Thread(target=heartbeat, daemon=True).start()
-    for _ in range(a.warmup):
-        loss = step()
+
+    # ---- CPU baseline first, so that the one JSON line can go out the moment the timed steps end
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.config, tl, H, Z, K)
+        say("cpu baseline: %.1f seq-ts/s on %d threads" % (cpu["value"], cpu["cores"]))
+
+    # ---- warm-up 1 (cold: workspace allocation, plan binding), warm-up 2 under the per-launch HIP events
     fence()
-    # Per-kernel HIP events (the roofline figures).  On one GPU they bracket the launches of the timed steps
-    # themselves.  With several ranks the timed region stays free of them (no per-launch events or pinned staging
-    # next to the collective), and rank 0 profiles one extra local step -- no all-reduce, no optimiser -- afterwards.
-    inline_prof = world == 1
-    if inline_prof:
+    loss = step()
+    fence()
+    say("cold warm-up step done")
+    if rank == 0:
         N.profile_start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    t1 = time.perf_counter()
+    loss = step()
+    fence()
+    prof_dt = time.perf_counter() - t1
+    prof = N.profile_stop() if rank == 0 else []
+    n_warm = 2
+    say("profiled warm-up step: %.3f s" % prof_dt)
+
+    # ---- how many more steps fit the budget (same decision on every rank)
+    left = a.budget - (time.perf_counter() - T_PROC0) - 5.0
+    afford = int(left / (prof_dt * 1.02))
+    if dist is not None:
+        tt = torch.tensor([afford], device="cuda", dtype=torch.int64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        afford = int(tt)
+    steps = max(min(a.steps, 3), min(a.steps, afford))
+    extra_warm = max(0, min(a.warmup - n_warm, afford - steps))
+    for _ in range(extra_warm):
         loss = step()
+    n_warm += extra_warm
+    say("timing %d steps (requested %d) after %d warm-ups (requested %d)" % (steps, a.steps, n_warm, a.warmup))
+
+    # ---- timed region: no profiler, no host work besides the launches; one device sync + clock read per step
+    fence()
+    t0 = time.perf_counter()
+    marks = [t0]
+    for _ in range(steps):
+        loss = step()
+        torch.cuda.synchronize()
+        marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
-    prof = N.profile_stop() if inline_prof else []
-    prof_steps = a.steps
-    if not inline_prof:
-        if rank == 0:
-            N.profile_start()
-            t1 = time.perf_counter()
-            opt.zero_grad()
-            model(x, mask, beta=1.0, temp=3.0, inv_batch=1.0 / B)["n_elbo"].backward()
-            torch.cuda.synchronize()
-            prof_dt = time.perf_counter() - t1
-            prof = N.profile_stop()
-            prof_steps = 1
-        fence()
+    per = torch.tensor([marks[i + 1] - marks[i] for i in range(steps)] + [dt], device="cuda", dtype=torch.float64)
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        dist.all_reduce(per, op=dist.ReduceOp.MAX)
         lv = loss["n_elbo"].detach().clone()
         dist.all_reduce(lv)
     else:
@@ -186,19 +273,25 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    ms_step = dt / a.steps * 1e3
-    value = B * T * a.steps / dt
+    per = per.tolist()
+    dt = per.pop()
+    med = sorted(per)[len(per) // 2] if len(per) % 2 else 0.5 * (sorted(per)[len(per) // 2 - 1] + sorted(per)[len(per) // 2])
+    ms_step = med * 1e3
+    value = B * T / med
 
-    prof_ms = dt * 1e3 if inline_prof else prof_dt * 1e3  # wall time of the profiled step(s)
+    prof_ms = prof_dt * 1e3  # wall time of the profiled step
     gemms = [p for p in prof if p["id"] < 18]
     dom = max(gemms, key=lambda p: p["ms"]) if gemms else None
     roof = None
     if dom:
         ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12
+        traffic, tsrc = pmc_traffic(a.config, B, T, dom["name"])
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom["name"], "dtype": "f32",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                "kernel": dom["name"], "dtype": "f32",
                 "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                "share_of_step": dom["ms"] / prof_ms}
+                "share_of_step": dom["ms"] / prof_ms,
+                "measured": "HIP events around every launch of one warm, untimed step"}
     others = []
     for p in prof:
         if dom is not None and p["id"] == dom["id"]:
@@ -213,18 +306,22 @@ def main():
                      frac=rate / 1e12 / PEAK_F32_MFMA_TFLOPS)
         others.append(e)
     out = {"metric": "train sequence-timesteps/sec (ELBO fwd+bwd)", "value": value, "unit": "sequence-timesteps/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "n_gpus": world, "steps": steps, "warmup": n_warm, "steps_requested": a.steps, "warmup_requested": a.warmup,
+           "ms_per_step": ms_step, "ms_per_step_mean": dt / steps * 1e3, "ms_per_step_min": min(per) * 1e3,
+           "ms_per_step_max": max(per) * 1e3, "statistic": "median of the timed steps (max over ranks per step)",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s: synthetic heterogeneous HMM, global batch %d, T=%d, D=%d (%d real/%d pos/%d bin/%d cat), "
                                   "h_dim=%d, z_dim=%d, K=%d, %d%% missing; fwd+bwd+allreduce+clip+Adam"
                                   % (a.config, B, T, len(tl), nr, npos, nb, len(cats), H, Z, K, int(miss * 100)),
                       "global_batch": B, "seq_len": T, "parallelism": "dp%d" % world,
-                      "micro_batch": model.micro_batch(T, Bl), "params": int(sum(p.numel() for p in model.parameters())),
+                      "micro_batch": micro[0], "micro_batches_per_rank": len(micro),
+                      "params": int(sum(p.numel() for p in model.parameters())),
                       "missing_frac": round(float(mask.float().mean()), 4)},
+           "wall_s": time.perf_counter() - T_PROC0, "budget_s": a.budget,
            "n_elbo": float(lv), "roofline": roof, "roofline_other_kernels": others}
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.config, tl, H, Z, K)
-    print(json.dumps(out))
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -35,7 +35,6 @@ static int g_pm = 0, g_pn = 0, g_pk = 0, g_pg = 0;
 void prof_shape(int M, int N, int K, int G) { g_pm = M; g_pn = N; g_pk = K; g_pg = G; }
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static std::vector<int*> g_prof_cnt_blocks;  // pinned, one per chunk while profiling
 static const std::vector<int>* g_rag_attr = nullptr;
 static const int* g_rag_cnt = nullptr;
 static int g_rag_ext = 0;
@@ -50,7 +49,11 @@ void prof_begin(int id, double work, hipStream_t s) {
     g_prof.push_back(r);
 }
 static bool prof_on() { return g_prof_on; }
-static void prof_keep_block(int* blk) { g_prof_cnt_blocks.push_back(blk); }
+// a plan is going away: records of ragged launches must not read its pinned counts any more
+static void prof_forget_counts(const int* lo, const int* hi) {
+    for (auto& r : g_prof)
+        if (r.rag_cnt >= lo && r.rag_cnt < hi) { r.rag_cnt = nullptr; r.rag_attr = nullptr; }
+}
 void prof_end(hipStream_t s) {
     if (!g_prof_on || g_prof.empty()) return;
     (void)hipEventRecord(g_prof.back().b, s);
@@ -105,6 +108,10 @@ struct shivae_plan {
     ScanWOff woff;
     size_t wpack_floats = 0;
     std::vector<void*> owned;  // device allocations to free
+    // pinned host ring of per-chunk observed-row counts (D ints per slot), written only while the HIP-event profiler
+    // is on: allocated once in shivae_plan_bind, never inside a step
+    int* cnt_host = nullptr;
+    int cnt_slots = 0, cnt_next = 0;
     // grouped-GEMM tables
     GroupTable b_l0_w, b_l0_wr;  // layer-0 weight gradient per attribute (ragged steps): main columns + the E % 128 remainder
     int l0_nmain = 0;
@@ -653,10 +660,10 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
             // are stored compactly -- row i of its column block = its i-th observed row of the chunk.
             SV_TRY(launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s));
             g_chunk_cnt_host = nullptr;
-            if (prof_on()) {
-                int* blk = nullptr;
-                SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&blk), (size_t)D * sizeof(int), hipHostMallocDefault));
-                prof_keep_block(blk);
+            if (prof_on() && p->cnt_host) {
+                // (a ring of 4 steps' worth of chunks: a profile session longer than that re-uses slots, and its
+                // older ragged records are then scaled by a later chunk's counts)
+                int* blk = p->cnt_host + (size_t)(p->cnt_next++ % p->cnt_slots) * D;
                 SV_CHECK_HIP(hipMemcpyAsync(blk, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
                 g_chunk_cnt_host = blk;
             }
@@ -900,9 +907,20 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
     return SHIVAE_OK;
 }
 
+static void release_bound(shivae_plan* p) {
+    for (void* d : p->owned) (void)hipFree(d);
+    p->owned.clear();
+    if (p->cnt_host) {
+        prof_forget_counts(p->cnt_host, p->cnt_host + (size_t)p->cnt_slots * p->D);
+        (void)hipHostFree(p->cnt_host);
+        p->cnt_host = nullptr;
+    }
+    p->cnt_slots = p->cnt_next = 0;
+}
+
 void shivae_plan_destroy(shivae_plan* plan) {
     if (!plan) return;
-    for (void* d : plan->owned) (void)hipFree(d);
+    release_bound(plan);
     delete plan;
 }
 
@@ -933,14 +951,24 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
     SV_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "plan_bind: workspace must be 256-B aligned");
     SV_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0,
                "plan_bind: parameter/gradient buffers must be 16-B aligned");
-    for (void* d : p->owned) (void)hipFree(d);
-    p->owned.clear();
+    release_bound(p);
     p->f_out.clear(); p->b_out_w.clear(); p->b_out_d.clear(); p->c_out.clear();
     p->ws = static_cast<char*>(ws);
     p->params = params;
     p->grads = grads;
-    // padding columns and the t=0 h_prev rows rely on the workspace starting at zero
-    SV_CHECK_HIP(hipMemset(ws, 0, p->ws_bytes));
+    // Padding columns and the t=0 h_prev rows rely on the workspace starting at zero.  Cleared in pieces of 1 GiB
+    // (asynchronously, one wait at the end of bind): a single fill of the whole workspace -- 170 GB at cfg3 -- is one
+    // dispatch whose size does not fit 32 bits, and the only step of the set-up that differed between the runs
+    // that survived `rocprofv3 --pmc` and the one that did not.
+    for (size_t off = 0; off < p->ws_bytes; off += (size_t)1 << 30)
+        SV_CHECK_HIP(hipMemsetAsync(p->ws + off, 0, std::min<size_t>((size_t)1 << 30, p->ws_bytes - off), nullptr));
+    {
+        const int64_t nchunks = (p->R + p->Rc - 1) / p->Rc;
+        p->cnt_slots = (int)std::max<int64_t>(64, std::min<int64_t>(4 * nchunks, 1 << 16));
+        SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->cnt_host), (size_t)p->cnt_slots * p->D * sizeof(int),
+                                   hipHostMallocDefault));
+        p->cnt_next = 0;
+    }
     SV_TRY(upload(p, p->attrs, &p->attrs_dev));
     std::vector<PackJob> wj, bj;
     build_pack_plan(p, wj, bj, true);
@@ -1118,8 +1146,6 @@ int shivae_profile_stop(double* out, int max_entries) {
     }
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
-    for (int* b : g_prof_cnt_blocks) (void)hipHostFree(b);
-    g_prof_cnt_blocks.clear();
     int n = 0;
     for (int i = 0; i < PROF_COUNT && n < max_entries; ++i)
         if (calls[i] > 0) { out[4 * n] = i; out[4 * n + 1] = calls[i]; out[4 * n + 2] = ms[i]; out[4 * n + 3] = work[i]; ++n; }

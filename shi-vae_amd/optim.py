@@ -15,7 +15,11 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def __init__(self, model, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, clip=None):
         self.model = model
-        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        # (weight_decay / amsgrad / ...: torch.optim.Adam's other defaults at their no-op values, so that a checkpoint
+        # written here loads into torch.optim.Adam and back)
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+                                                        maximize=False, foreach=None, capturable=False,
+                                                        differentiable=False, fused=None, decoupled_weight_decay=False))
         self.clip = clip
         dev = model.flat_params.device
         self._m = torch.zeros_like(model.flat_params)

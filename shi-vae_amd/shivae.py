@@ -276,6 +276,15 @@ class ShiVAE(nn.Module):
             nb = max(16, int(bm * budget / ws * 0.98) // 16 * 16)
             bm = nb if nb < bm else max(16, bm - 16)
 
+    def micro_batches(self, T, B):
+        """Per-call batch sizes the step is run in: equal-sized micro-batches (one plan, no re-binding), multiples
+        of the 16-sequence scan tile, each fitting the workspace budget."""
+        bm = self.micro_batch(T, B)
+        if bm < B:
+            nmb = -(-B // bm)
+            bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
+        return [min(bm, B - b0) for b0 in range(0, B, bm)]
+
     def _activate(self, T, B):
         plan = self._make_plan(T, B)
         if self._active is plan:
@@ -326,10 +335,7 @@ class ShiVAE(nn.Module):
         inv_batch = 1.0 / B if inv_batch is None else float(inv_batch)
         losses = torch.zeros(16, dtype=torch.float32, device=dev)
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
-        bm = self.micro_batch(T, B)
-        if bm < B:  # equal-sized micro-batches (one plan, no re-binding), multiples of the 16-sequence scan tile
-            nmb = -(-B // bm)
-            bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
+        bm = self.micro_batches(T, B)[0]
         self._grow_chunk(T, min(bm, B))
         outs = {w: [] for w in (collect or [])}
         persum = []
@@ -540,10 +546,7 @@ class ShiVAE(nn.Module):
         T, B = int(ts), int(batch_size)
         u, eps = self._draw_noise(T, B)
         O, L = N.O, N.lib()
-        bm = self.micro_batch(T, B)
-        if bm < B:
-            nmb = -(-B // bm)
-            bm = min(bm, -(-(-(-B // nmb)) // 16) * 16)
+        bm = self.micro_batches(T, B)[0]
         want = [O["Z"], O["Z_MEAN"], O["Z_STD"], O["S"], O["S_PROBS"], O["DEC_PARAMS"]]
         outs = {w: [] for w in want}
         for b0 in range(0, B, bm):
@@ -573,9 +576,9 @@ class ShiVAE(nn.Module):
         batch shard with inv_batch = 1/B_global, so the sum IS the global-batch gradient."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # The gradient buffer is complete once the step's kernels have run: wait for them on the host before
-            # handing it to the collective (one wait per multi-second step).  RCCL would order itself behind the
-            # stream anyway; the gloo path used in CPU/1-GPU rehearsals was seen to hang without it.
-            if self._gflat.is_cuda:
+            # RCCL orders itself behind the step's kernels on the current stream: no host wait.  gloo (CPU / 1-GPU
+            # rehearsals) stages device tensors through the host from its own threads, so there the host waits for
+            # the step first.
+            if self._gflat.is_cuda and dist.get_backend() != "nccl":
                 torch.cuda.current_stream().synchronize()
             dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)

@@ -7,12 +7,16 @@ import math
 import torch
 
 
-def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda", chunk=1024):
+def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda", chunk=512, seq0=0):
+    """Sequences [seq0, seq0 + B) of the synthetic set `seed`.  Every block of `chunk` sequences has a generator
+    stream of its own (seeded by its block index), so a rank that asks for its shard of a global batch gets exactly
+    the rows a single process would have generated there (seq0 must sit on a block boundary)."""
+    assert seq0 % chunk == 0, "a shard starts on a block of %d sequences" % chunk
     g = torch.Generator(device=device)
-    g.manual_seed(int(seed))
     xs, ms = [], []
     for b0 in range(0, B, chunk):
         b = min(chunk, B - b0)
+        g.manual_seed(int(seed) * 1000003 + (seq0 + b0) // chunk)
         # hidden chain: stay with prob 0.9, else jump to a uniformly random state
         st = torch.empty(T, b, dtype=torch.long, device=device)
         cur = torch.randint(0, n_states, (b,), generator=g, device=device)

@@ -149,17 +149,34 @@ class Trainer:
         epoch_loss, _ = self.init_loss_dict()
         beta = self.annealing_weight.update_beta(epoch)
         self.model.train()
+        import torch.distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         for data, mask, _attrs in train_loader:
             data, mask = self.preprocess_batch(data, mask)
             data = utils.zero_fill(data, mask)
             self.optimizer.zero_grad()
-            loss_dict = self.model(data, mask=mask, beta=beta, temp=self.temp)
+            inv_batch = None
+            if world > 1:
+                # data parallel over the batch: every rank scales by 1/B_global (ragged last batches: the summed
+                # count), so the all-reduced SUM of the flat gradients is the global-batch gradient that
+                # clip_grad_norm_ sees in the reference (trainers.py:222)
+                cnt = torch.tensor([float(data.shape[1])], device=data.device)
+                dist.all_reduce(cnt)
+                inv_batch = 1.0 / float(cnt.item())
+            loss_dict = self.model(data, mask=mask, beta=beta, temp=self.temp, inv_batch=inv_batch)
             n_elbo = loss_dict['n_elbo']
             n_elbo.backward()
+            self.model.allreduce_grads()
+            if world > 1:
+                # the 9 logged scalars are per-rank shares of the global means: sum them; a NaN on any rank becomes
+                # a NaN on all of them, so every rank takes the same branch below (none is left inside a collective)
+                vals = torch.stack([loss_dict[k].detach() for k in self.loss_list])
+                dist.all_reduce(vals)
+                loss_dict = {k: vals[i] for i, k in enumerate(self.loss_list)}
+                n_elbo = loss_dict['n_elbo']
             if np.isnan(n_elbo.detach().cpu().numpy()):
                 print('Encountered NaN, stopping training. Please check the learning_rate settings and the momentum.')
                 break
-            self.model.allreduce_grads()
             if isinstance(self.optimizer, FusedClipAdam):
                 self.optimizer.step(clip=self.clip)
             else:
