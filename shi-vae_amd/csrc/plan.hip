@@ -729,6 +729,10 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
 
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
+        // (SHIVAE_SYNC_CHUNKS=1: the host waits for each row chunk.  For runs under `rocprofv3 --pmc`, whose
+        // per-dispatch buffers do not survive thousands of launches enqueued ahead of the GPU -- DESIGN.md s.4)
+        static const bool sync_chunks = [] { const char* f = getenv("SHIVAE_SYNC_CHUNKS"); return f && atoi(f) != 0; }();
+        if (sync_chunks) SV_CHECK_HIP(hipStreamSynchronize(s));
     }
     g_chunk_cnt_host = nullptr;
 

@@ -17,13 +17,14 @@ def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda"
     for b0 in range(0, B, chunk):
         b = min(chunk, B - b0)
         g.manual_seed(int(seed) * 1000003 + (seq0 + b0) // chunk)
-        # hidden chain: stay with prob 0.9, else jump to a uniformly random state
-        st = torch.empty(T, b, dtype=torch.long, device=device)
-        cur = torch.randint(0, n_states, (b,), generator=g, device=device)
-        for t in range(T):
-            jump = torch.rand(b, generator=g, device=device) < 0.1
-            cur = torch.where(jump, torch.randint(0, n_states, (b,), generator=g, device=device), cur)
-            st[t] = cur
+        # hidden chain: stay with prob 0.9, else jump to a uniformly random state.  No loop over t: the state at t
+        # is the state drawn at the last jump at or before t (t = 0 always draws).
+        jump = torch.rand(T, b, generator=g, device=device) < 0.1
+        jump[0] = True
+        drawn = torch.randint(0, n_states, (T, b), generator=g, device=device)
+        tt = torch.arange(T, device=device).unsqueeze(1).expand(T, b)
+        last = torch.where(jump, tt, torch.zeros_like(tt)).cummax(0).values
+        st = drawn.gather(0, last)
         cols, mcols = [], []
         for d, ty in enumerate(types_list):
             kind, dim = ty["type"], int(ty["dim"])

@@ -94,3 +94,16 @@ def test_plan_layout_is_disjoint_and_complete():
         assert a[1] <= b[0]
     assert leaves[-1][1] <= p.num_params
     assert p.x_dim == 1 + 1 + 1 + 4 + 8 and p.p_dim == 2 + 2 + 1 + 3 + 7
+
+
+def test_synthetic_batch_shards_by_sequence_block():
+    """bench.py --gpus N: rank r generates exactly rows [r*B/N, (r+1)*B/N) of the single-process batch."""
+    import torch
+    from shivae_amd.synth import synth_batch
+    tl = shivae_amd.utils.make_types_list(2, 1, 1, [3, 4])
+    x, m = synth_batch(tl, 50, 64, miss=0.3, seed=9, device="cpu", chunk=16)
+    for r in range(4):
+        xs, ms = synth_batch(tl, 50, 16, miss=0.3, seed=9, device="cpu", chunk=16, seq0=16 * r)
+        assert torch.equal(xs, x[:, 16 * r:16 * (r + 1)]) and torch.equal(ms, m[:, 16 * r:16 * (r + 1)])
+    assert 0.2 < float(m.float().mean()) < 0.4
+    assert float(x[m].abs().max()) == 0.0  # zero-filled where missing
