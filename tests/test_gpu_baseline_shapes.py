@@ -26,6 +26,35 @@ MIXES = {
 }
 
 
+def _dekink_decoder(P, tl, emb, delta=2e-5, bump=1e-3):
+    """ReLU gates are decided in fp32 on the GPU and in fp64 by the oracle.  These shapes have ~2e7 decoder
+    ReLU inputs, so a dozen of them sit within fp32 rounding of zero, the two sides gate them differently, and with
+    only T*B = 72 rows one flipped gate moves a layer's gradient by per cent (seen: 0.155 of max|grad| on one
+    dec.0.weight, identical in the dense and the mask-aware form).  That is the test's conditioning, not the
+    kernels': nudge the bias of every decoder unit that has an input within `delta` of zero, layer by layer."""
+    a_in = emb.reshape(-1, emb.shape[-1]).astype(np.float64)
+    moved = 0
+    for t in tl:
+        pre = "dec.decoder_dict.%s." % t["name"]
+        layers = ["dec.0", "dec.2", "dec.4"] + {"bin": ["dec_p.0"], "cat": ["dec_p_cat.0"]}.get(t["type"], [])
+        a = a_in
+        for L in layers:
+            W = P[pre + L + ".weight"].astype(np.float64)
+            b = P[pre + L + ".bias"].astype(np.float32)
+            for _ in range(16):
+                z = a @ W.T + b.astype(np.float64)
+                near = (np.abs(z) < delta).any(axis=0)
+                if not near.any():
+                    break
+                b[near] += np.float32(bump)
+                moved += int(near.sum())
+            else:
+                raise AssertionError("could not move %s%s off its kinks" % (pre, L))
+            P[pre + L + ".bias"] = b
+            a = np.maximum(z, 0)
+    return moved
+
+
 @pytest.mark.parametrize("name", list(MIXES))
 def test_step_at_baseline_attribute_mix(name):
     tl, T, B, H, Z, K, miss, chunk, micro = MIXES[name]
@@ -40,6 +69,9 @@ def test_step_at_baseline_attribute_mix(name):
     beta, temp = 0.9, 2.0
     om = so.OracleShiVAE(P, tl, H, Z, K, True)
     c = om.forward(x, mask, u, eps, beta, temp)
+    if _dekink_decoder(P, tl, c["emb"]):       # (the decoder's input does not depend on the decoder's biases)
+        om = so.OracleShiVAE(P, tl, H, Z, K, True)
+        c = om.forward(x, mask, u, eps, beta, temp)
     G = om.backward()
     m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
     m.chunk_rows = chunk                       # >= 2 row chunks per micro-batch
@@ -53,11 +85,12 @@ def test_step_at_baseline_attribute_mix(name):
     for k in shivae_amd.LOSS_KEYS:
         np.testing.assert_allclose(float(loss[k]), c["losses"][k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
     loss["n_elbo"].backward()
-    worst = ("", 0.0)
+    bad = []
     for k, p in m.named_parameters():
         err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
-        worst = max(worst, (k, err), key=lambda t: t[1])
-    assert worst[1] < GRAD_RTOL, worst
+        if not err < GRAD_RTOL:
+            bad.append((k, float(err)))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
     # forward tensors of the dense (imputation) form of the same decoder
     m.eval()
     m.set_noise(u, eps)
