@@ -90,6 +90,21 @@ enum {
     SHIVAE_O_ROWLOSS,    /* per-timestep ELBO terms [6]: nll_real,nll_pos,nll_bin,nll_cat,kl_z,kl_s */
     SHIVAE_O_H_PREV,     /* h_{t-1}           [H] */
     SHIVAE_O_PHI_Z,      /*                   [H] */
+    /* records of the recurrent scans (what autograd would keep for shivae.py:102-143), for kernel-level parity */
+    SHIVAE_O_A_S,        /* relu(phi_x_s.0 [x,h])           [H]  encoders.py:83 */
+    SHIVAE_O_LOGITS,     /* LeakyReLU(phi_x_s.2 a_s)        [K]  encoders.py:56-57 */
+    SHIVAE_O_E1,         /* relu(enc.0 [phi_x,s,h])         [H]  encoders.py:91 */
+    SHIVAE_O_E2,         /* relu(enc.2 e1)                  [H] */
+    SHIVAE_O_GATES,      /* LSTM gates i,f,g,o after their nonlinearity [4H]  shivae.py:136 */
+    SHIVAE_O_C_NEW,      /* c_t                             [H] */
+    SHIVAE_O_D_GATES,    /* after shivae_scan_bwd / a training step: d loss / d gate pre-activations [4H] */
+    SHIVAE_O_D_PHIZ_PRE, /* d / d (phi_z.0 z + b)           [H] */
+    SHIVAE_O_D_MU,       /* d / d enc_mean output           [Z] */
+    SHIVAE_O_D_STD_PRE,  /* d / d (enc_std.0 e2 + b)        [Z] */
+    SHIVAE_O_D_E2_PRE,   /* d / d (enc.2 e1 + b)            [H] */
+    SHIVAE_O_D_E1_PRE,   /* d / d (enc.0 [phi_x,s,h] + b)   [H] */
+    SHIVAE_O_D_LOGITS_PRE, /* d / d (phi_x_s.2 a_s + b)     [K] */
+    SHIVAE_O_D_AS_PRE,   /* d / d (phi_x_s.0 [x,h] + b)     [H] */
     SHIVAE_O_COUNT
 };
 
@@ -134,6 +149,43 @@ int shivae_plan_bind(shivae_plan* plan, void* workspace_dev, size_t workspace_by
 int shivae_elbo_step(shivae_plan* plan, const float* x_dev, const uint8_t* mask_dev, const float* u_dev,
                      const float* eps_dev, float beta, float temp, float inv_batch, int flags,
                      float* losses_dev, shivae_stream stream);
+
+/* ---- the phases of the step (SURVEY.md 8b minimum set), for callers that compose their own ------------------
+ * shivae_elbo_step == scan_fwd; prior_kl; decoder_nll; [scan_bwd;] loss_reduce on one bound plan and stream.
+ * All of them work on the plan's workspace records; gradients are ACCUMULATED into the bound gradient buffer.
+ *
+ * shivae_scan_fwd -- north_star kernel (1): ShiVAE.feed2model's time loop without the prior and decoder
+ *   (src/models/shivae.py:102-143; GMEncoder.forward src/models/encoders.py:70-98; Gumbel-softmax and Gaussian
+ *   reparameterisation fused, src/models/samplers.py:23-62; nn.LSTM single step shivae.py:136): the x-only encoder
+ *   GEMMs over all rows, then ONE persistent kernel looping over t.  Afterwards shivae_get_output gives Z, Z_MEAN,
+ *   Z_STD, S, S_PROBS, PHI_Z, H_PREV and the records A_S, LOGITS, E1, E2, GATES, C_NEW. */
+int shivae_scan_fwd(shivae_plan* plan, const float* x_dev, const float* u_dev, const float* eps_dev, float temp,
+                    shivae_stream stream);
+/* prior network + KL(q(z)||p(z)) + KL(q(s)||U) over all rows (shivae.py:124-127, base_missvae.py:287-343), rowloss
+ * columns 4,5; without SHIVAE_STEP_FORWARD_ONLY also their gradients (scaled by beta*inv_batch), the prior network's
+ * backward, and the START of this step's d_emb records (zero + the prior network's input gradient). */
+int shivae_prior_kl(shivae_plan* plan, float beta, float inv_batch, int flags, shivae_stream stream);
+/* HeterDecoder.forward over all rows (src/models/decoders.py:109-176) + heter_nll (base_missvae.py:233-285) in row
+ * chunks, rowloss columns 0..3; without SHIVAE_STEP_FORWARD_ONLY each chunk's backward runs right behind its
+ * forward (decoder activations never exist for more than one chunk, so forward and backward are ONE call): weight
+ * gradients are accumulated, the input gradient is ADDED to the d_emb records (call shivae_prior_kl first, which
+ * zeroes them). */
+int shivae_decoder_nll(shivae_plan* plan, const float* x_dev, const uint8_t* mask_dev, float inv_batch, int flags,
+                       shivae_stream stream);
+/* north_star kernel (4): the reverse-time scan (what autograd does for shivae.py:102-143 -- full BPTT, h and c are
+ * never detached) + the weight gradients of the recurrent cell and the phi_x backward, after shivae_scan_fwd on the
+ * same plan, x, u, eps, temp.  The gradients that reach the chain from outside are either the records accumulated
+ * by shivae_prior_kl / shivae_decoder_nll (pass NULL) or given here, unpadded:
+ *   d_emb_dev   [T][B][2H+K]  d loss / d cat[phi_z_t, s_t, h_{t-1}]  (decoders.py:127 order)
+ *   dmu_dev, dstd_dev [T][B][Z]  d loss / d z_mean, d z_std          (the KL term's part)
+ *   dlogits_dev [T][B][K]     d loss / d s logits through s_probs
+ * Afterwards shivae_get_output gives the D_* records. */
+int shivae_scan_bwd(shivae_plan* plan, const float* x_dev, const float* u_dev, const float* eps_dev, float temp,
+                    const float* d_emb_dev, const float* dmu_dev, const float* dstd_dev, const float* dlogits_dev,
+                    shivae_stream stream);
+/* base_missvae.py:211-230: per-sequence sums of the rowloss records over t, then the 9 batch means, ACCUMULATED
+ * into losses_dev (as shivae_elbo_step) */
+int shivae_loss_reduce(shivae_plan* plan, float beta, float inv_batch, float* losses_dev, shivae_stream stream);
 
 /* ShiVAE.sample_from_prior (src/models/shivae.py:156-214): generation from the prior over plan.T steps for
  * plan.B sequences with explicit noise u[T][B][K] (Gumbel uniforms) and eps[T][B][Z].  Afterwards

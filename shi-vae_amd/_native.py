@@ -17,7 +17,9 @@ _P_NAMES = ["PHIX0_W", "PHIX0_B", "PHIX2_W", "PHIX2_B", "XS0_W", "XS0_B", "XS2_W
             "RNN_BHH", "DEC0_W", "DEC0_B", "DEC2_W", "DEC2_B", "DEC4_W", "DEC4_B", "HEAD0_W", "HEAD0_B",
             "HEADMEAN_W", "HEADMEAN_B", "HEADSTD_W", "HEADSTD_B", "HEADOUT_W", "HEADOUT_B"]
 P = {n: i for i, n in enumerate(_P_NAMES)}
-_O_NAMES = ["Z", "Z_MEAN", "Z_STD", "ZP_MEAN", "ZP_STD", "S", "S_PROBS", "DEC_PARAMS", "ROWLOSS", "H_PREV", "PHI_Z"]
+_O_NAMES = ["Z", "Z_MEAN", "Z_STD", "ZP_MEAN", "ZP_STD", "S", "S_PROBS", "DEC_PARAMS", "ROWLOSS", "H_PREV", "PHI_Z",
+            "A_S", "LOGITS", "E1", "E2", "GATES", "C_NEW", "D_GATES", "D_PHIZ_PRE", "D_MU", "D_STD_PRE", "D_E2_PRE",
+            "D_E1_PRE", "D_LOGITS_PRE", "D_AS_PRE"]
 O = {n: i for i, n in enumerate(_O_NAMES)}
 STEP_FORWARD_ONLY, STEP_KEEP_PARAMS = 1, 2
 SCALE_TRANSPOSE, SCALE_ZERO_FILL, SCALE_F64 = 1, 2, 4
@@ -28,6 +30,7 @@ EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 1
 SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_plan_destroy",
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
            "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
+           "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
            "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
            "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start",
@@ -72,6 +75,11 @@ def lib():
     L.shivae_plan_workspace_bytes.restype = C.c_size_t
     L.shivae_plan_bind.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.shivae_elbo_step.argtypes = [vp, vp, vp, vp, vp, cf, cf, cf, ci, vp, vp]
+    L.shivae_scan_fwd.argtypes = [vp, vp, vp, vp, cf, vp]
+    L.shivae_prior_kl.argtypes = [vp, cf, cf, ci, vp]
+    L.shivae_decoder_nll.argtypes = [vp, vp, vp, cf, ci, vp]
+    L.shivae_scan_bwd.argtypes = [vp, vp, vp, vp, cf, vp, vp, vp, vp, vp]
+    L.shivae_loss_reduce.argtypes = [vp, cf, cf, vp, vp]
     L.shivae_sample_prior.argtypes = [vp, vp, vp, cf, vp]
     L.shivae_get_output.argtypes = [vp, ci, vp, vp]
     L.shivae_output_width.argtypes = [vp, ci]

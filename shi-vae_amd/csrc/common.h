@@ -190,6 +190,8 @@ int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, f
 int launch_expand_add_emb(const float* dembc, int ldc, int H, int K, float* d_emb, int Ep, int Hp, int Kp, int rows,
                           hipStream_t stream);
 int launch_unpad_copy(const float* src, int ld, int col0, int width, float* dst, int64_t rows, hipStream_t stream);
+int launch_copy2d(const float* src, int lds, int col0, int width, float* dst, int ldd, int dcol0, int64_t rows,
+                  hipStream_t stream);
 int launch_transpose(const float* in, float* out, int R, int C, int batch, size_t in_stride, size_t out_stride,
                      hipStream_t stream);
 int launch_sqnorm(const float* buf, int64_t n, float* scratch, float* out, hipStream_t stream);

@@ -33,14 +33,14 @@ __global__ void expand_add_emb_kernel(const float* __restrict__ dembc, int ldc, 
     }
 }
 
-// dst[r][0:width] = src[r][col0 : col0+width]
-__global__ void unpad_copy_kernel(const float* __restrict__ src, int ld, int col0, int width,
-                                  float* __restrict__ dst, size_t rows) {
+// dst[r][dcol0 : dcol0+width] = src[r][col0 : col0+width]   (row strides lds / ldd)
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, int col0, int width, float* __restrict__ dst,
+                              int ldd, int dcol0, size_t rows) {
     const size_t n = rows * width;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / width;
         const int c = (int)(i % width);
-        dst[i] = src[r * ld + col0 + c];
+        dst[r * ldd + dcol0 + c] = src[r * lds + col0 + c];
     }
 }
 
@@ -90,12 +90,17 @@ int launch_expand_add_emb(const float* dembc, int ldc, int H, int K, float* d_em
     return SHIVAE_OK;
 }
 
-int launch_unpad_copy(const float* src, int ld, int col0, int width, float* dst, int64_t rows, hipStream_t stream) {
+int launch_copy2d(const float* src, int lds, int col0, int width, float* dst, int ldd, int dcol0, int64_t rows,
+                  hipStream_t stream) {
     if (rows <= 0 || width <= 0) return SHIVAE_OK;
-    hipLaunchKernelGGL(unpad_copy_kernel, dim3(grid_for((size_t)rows * width)), dim3(256), 0, stream, src, ld, col0,
-                       width, dst, (size_t)rows);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)rows * width)), dim3(256), 0, stream, src, lds, col0,
+                       width, dst, ldd, dcol0, (size_t)rows);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
+}
+
+int launch_unpad_copy(const float* src, int ld, int col0, int width, float* dst, int64_t rows, hipStream_t stream) {
+    return launch_copy2d(src, ld, col0, width, dst, width, 0, rows, stream);
 }
 
 // ---------------------------------------------------------------- global gradient norm (deterministic)

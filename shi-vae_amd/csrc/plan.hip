@@ -546,28 +546,24 @@ static ScanArgs scan_args(shivae_plan* p, const float* u, const float* eps, floa
     return a;
 }
 
-// ------------------------------------------------------------ the step
-static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float* u, const float* eps, float beta,
-                float temp, float inv_batch, int flags, float* losses, hipStream_t s) {
-    const bool grad = !(flags & SHIVAE_STEP_FORWARD_ONLY);
-    const bool keep = flags & SHIVAE_STEP_KEEP_PARAMS;
-    const int H = p->H, Z = p->Z, K = p->K, X = p->X, D = p->D, E = p->E, P = p->P;
-    const int Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep, E4 = p->E4;
+// ------------------------------------------------------------ the step, phase by phase
+// Each phase is also an entry point of the C ABI (shivae_scan_fwd, shivae_prior_kl, shivae_decoder_nll,
+// shivae_scan_bwd); shivae_elbo_step is their composition.
+static double scan_flops(const shivae_plan* p) {
+    // serial-chain flops per (t,b): SURVEY.md 8d (k2 h-part, k2 out, k4 s+h parts, enc.2, mean/std, phi_z, LSTM)
+    const double H = p->H, Z = p->Z, K = p->K;
+    return 2.0 * (H * H + H * K + (H + K) * H + H * H + 2.0 * H * Z + Z * H + 8.0 * H * H) * (double)p->R;
+}
+
+// Phase 1: packed scan weights, the x-only encoder GEMMs over all rows, the forward scan
+// (encoders.py:70-98, shivae.py:102-143).
+static int phase_scan_fwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, hipStream_t s) {
+    const int H = p->H, X = p->X, E = p->E, Hp = p->Hp;
     const int R = (int)p->R;
     const Tensor* g = p->glob;
-    const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
-
-    // 0. scan weights in MFMA operand order (parameters change every optimiser step)
+    const int NT = GEMM_NT;
+    // scan weights in MFMA operand order (parameters change every optimiser step)
     SV_TRY(launch_pack(p->wjobs_dev, p->n_wjobs, p->bjobs_dev, p->n_bjobs, p->wsf("wpack"), s));
-
-    if (grad) {
-        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC0_W]), p->wsf("wt0"), D * 2 * H, E, 1, 0, 0, s));
-        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC2_W]), p->wsf("wt2"), H, 2 * H, D, (size_t)H * 2 * H, (size_t)H * 2 * H, s));
-        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC4_W]), p->wsf("wt4"), H, H, D, (size_t)H * H, (size_t)H * H, s));
-        if (p->nbc > 0)
-            SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_HEAD0_W]), p->wsf("wth0"), H, H, p->nbc, (size_t)H * H, (size_t)H * H, s));
-    }
-
     // 1. h-independent encoder parts, batched over all T*B rows (encoders.py:82, x/phi_x halves of :83,:91)
     float *p1 = p->wsf("p1"), *phx = p->wsf("phx"), *xs_pre = p->wsf("xs_pre"), *ex_pre = p->wsf("ex_pre");
     SV_TRY(gemm1(NT, R, H, X, x, X, p->prm(g[SHIVAE_P_PHIX0_W]), X, p1, Hp, p->prm(g[SHIVAE_P_PHIX0_B]), nullptr, 0,
@@ -579,24 +575,31 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
     SV_TRY(gemm1(NT, R, H, H, phx, Hp, p->prm(g[SHIVAE_P_E0_W]), E, ex_pre, Hp, p->prm(g[SHIVAE_P_E0_B]), nullptr, 0,
                  EPI_BIAS, s));
 
-    // 2. the serial chain
+    // the serial chain
     ScanArgs sa = scan_args(p, u, eps, temp);
-    // serial-chain flops per (t,b): SURVEY.md 8d (k2 h-part, k2 out, k4 s+h parts, enc.2, mean/std, phi_z, LSTM)
-    const double scan_flops = 2.0 * ((double)H * H + (double)H * K + (double)(H + K) * H + (double)H * H +
-                                     2.0 * H * Z + (double)Z * H + 8.0 * H * H) * (double)R;
-    prof_begin(PROF_SCAN_FWD, scan_flops, s);
+    prof_begin(PROF_SCAN_FWD, scan_flops(p), s);
     SV_TRY(launch_scan(sa, false, s));
     prof_end(s);
+    return SHIVAE_OK;
+}
 
+// Phase 2: prior network + both KL terms (+ their gradients and the prior network's backward) over ALL rows
+// (shivae.py:124-127, base_missvae.py:287-343).  With gradients it starts the d_emb records of this step: zero,
+// plus the prior network's input gradient; the decoder phase adds its part.
+static int phase_prior_kl(shivae_plan* p, float beta, float inv_batch, bool grad, hipStream_t s) {
+    const int H = p->H, Z = p->Z, K = p->K;
+    const int Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep;
+    const int R = (int)p->R;
+    const Tensor* g = p->glob;
+    const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
     if (grad) SV_CHECK_HIP(hipMemsetAsync(d_emb, 0, (size_t)R * Ep * sizeof(float), s));
 
     const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
                 *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
     const float kz = beta * inv_batch;
-    // 3a. prior network + both KL terms + prior backward over ALL rows (blocks of <= 4M rows keep the GEMM
-    //     grids legal): shivae.py:124-127, base_missvae.py:287-343.  Scratch is borrowed from record
-    //     buffers that are only written after this point (by the backward scan / phi_x backward).
+    // Blocks of <= 4M rows keep the GEMM grids legal.  Scratch is borrowed from record buffers that are only
+    // written after this point (by the backward scan / phi_x backward).
     {
         float *prc_all = p->wsf("d_phx_pre"), *dprc_all = p->wsf("d_p1_pre");
         float *dmup_all = p->wsf("d_mu"), *dsdp_all = p->wsf("d_sd_pre");
@@ -641,8 +644,28 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         }
     }
 
-    // 3b. the decoder and its likelihood, in row chunks (decoders.py:109-176, base_missvae.py:233-285),
-    //     each chunk's backward right behind its forward
+    return SHIVAE_OK;
+}
+
+// Phase 3: the decoder and its likelihood, in row chunks (decoders.py:109-176, base_missvae.py:233-285), each
+// chunk's backward right behind its forward (activations only ever exist for one chunk); input gradients are
+// ADDED to the d_emb records, weight gradients to the bound gradient buffer.
+static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, float inv_batch, int flags, hipStream_t s) {
+    const bool grad = !(flags & SHIVAE_STEP_FORWARD_ONLY);
+    const bool keep = flags & SHIVAE_STEP_KEEP_PARAMS;
+    const int H = p->H, K = p->K, X = p->X, D = p->D, E = p->E, P = p->P;
+    const int Hp = p->Hp, Kp = p->Kp, Ep = p->Ep, E4 = p->E4;
+    const int R = (int)p->R;
+    const Tensor* g = p->glob;
+    const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
+    float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
+    if (grad) {  // K-contiguous copies of the decoder weights for the input-gradient GEMMs
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC0_W]), p->wsf("wt0"), D * 2 * H, E, 1, 0, 0, s));
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC2_W]), p->wsf("wt2"), H, 2 * H, D, (size_t)H * 2 * H, (size_t)H * 2 * H, s));
+        SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC4_W]), p->wsf("wt4"), H, H, D, (size_t)H * H, (size_t)H * H, s));
+        if (p->nbc > 0)
+            SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_HEAD0_W]), p->wsf("wth0"), H, H, p->nbc, (size_t)H * H, (size_t)H * H, s));
+    }
     float *embc = p->wsf("embc"), *dembc = p->wsf("dembc");
     float *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
     float *da0 = p->wsf("da0");
@@ -735,10 +758,21 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         if (sync_chunks) SV_CHECK_HIP(hipStreamSynchronize(s));
     }
     g_chunk_cnt_host = nullptr;
+    return SHIVAE_OK;
+}
 
-    if (grad) {
-        // 4. reverse-time scan
-        prof_begin(PROF_SCAN_BWD, 2.0 * scan_flops, s);
+// Phase 4: reverse-time scan over the d_emb / dmu_ext / dsd_ext / dlg_kl records (BPTT over the whole T:
+// shivae.py:102-137 never detaches), then the weight gradients of the cell and the phi_x backward.
+static int phase_scan_bwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, hipStream_t s) {
+    const int H = p->H, Z = p->Z, K = p->K, X = p->X, E = p->E;
+    const int Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep;
+    const int R = (int)p->R;
+    const Tensor* g = p->glob;
+    const int NN = GEMM_NN, TN = GEMM_TN;
+    float *emb = p->wsf("emb"), *p1 = p->wsf("p1"), *phx = p->wsf("phx");
+    ScanArgs sa = scan_args(p, u, eps, temp);
+    {
+        prof_begin(PROF_SCAN_BWD, 2.0 * scan_flops(p), s);
         SV_TRY(launch_scan(sa, true, s));
         prof_end(s);
         // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics)
@@ -784,8 +818,18 @@ static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float
         SV_TRY(colsum1(R, H, Hp, d_p1, p->grd(g[SHIVAE_P_PHIX0_B]), s));
     }
 
-    // 7. sum per-timestep terms over t (fixed order), then the batch means (base_missvae.py:211-230)
-    SV_TRY(launch_loss_reduce(rowloss, p->wsf("persum"), p->T, p->B, beta, inv_batch, losses, s));
+    return SHIVAE_OK;
+}
+
+static int step(shivae_plan* p, const float* x, const uint8_t* mask, const float* u, const float* eps, float beta,
+                float temp, float inv_batch, int flags, float* losses, hipStream_t s) {
+    const bool grad = !(flags & SHIVAE_STEP_FORWARD_ONLY);
+    SV_TRY(phase_scan_fwd(p, x, u, eps, temp, s));
+    SV_TRY(phase_prior_kl(p, beta, inv_batch, grad, s));
+    SV_TRY(phase_decoder(p, x, mask, inv_batch, flags, s));
+    if (grad) SV_TRY(phase_scan_bwd(p, x, u, eps, temp, s));
+    // sum per-timestep terms over t (fixed order), then the batch means (base_missvae.py:211-230)
+    SV_TRY(launch_loss_reduce(p->wsf("rowloss"), p->wsf("persum"), p->T, p->B, beta, inv_batch, losses, s));
     p->last_flags = flags;
     return SHIVAE_OK;
 }
@@ -996,6 +1040,63 @@ int shivae_elbo_step(shivae_plan* p, const float* x, const uint8_t* mask, const 
     return step(p, x, mask, u, eps, beta, temp, inv_batch, flags, losses, static_cast<hipStream_t>(stream));
 }
 
+#define SV_BOUND(name)                                                                                   \
+    if (!p->bound) {                                                                                     \
+        set_error(name ": plan has no workspace/parameters bound (call shivae_plan_bind)");              \
+        return SHIVAE_ERR_UNBOUND;                                                                       \
+    }
+
+int shivae_scan_fwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, shivae_stream stream) {
+    SV_REQUIRE(p && x && u && eps, "scan_fwd: null argument");
+    SV_BOUND("scan_fwd");
+    SV_REQUIRE(temp > 0.f, "scan_fwd: temperature must be > 0");
+    p->last_flags = SHIVAE_STEP_FORWARD_ONLY;
+    return phase_scan_fwd(p, x, u, eps, temp, static_cast<hipStream_t>(stream));
+}
+
+int shivae_prior_kl(shivae_plan* p, float beta, float inv_batch, int flags, shivae_stream stream) {
+    SV_REQUIRE(p, "prior_kl: null argument");
+    SV_BOUND("prior_kl");
+    return phase_prior_kl(p, beta, inv_batch, !(flags & SHIVAE_STEP_FORWARD_ONLY), static_cast<hipStream_t>(stream));
+}
+
+int shivae_decoder_nll(shivae_plan* p, const float* x, const uint8_t* mask, float inv_batch, int flags,
+                       shivae_stream stream) {
+    SV_REQUIRE(p && x && mask, "decoder_nll: null argument");
+    SV_BOUND("decoder_nll");
+    p->last_flags = flags;
+    return phase_decoder(p, x, mask, inv_batch, flags, static_cast<hipStream_t>(stream));
+}
+
+int shivae_scan_bwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, const float* d_emb,
+                    const float* dmu, const float* dstd, const float* dlogits, shivae_stream stream) {
+    SV_REQUIRE(p && x && u && eps, "scan_bwd: null argument");
+    SV_BOUND("scan_bwd");
+    SV_REQUIRE(temp > 0.f, "scan_bwd: temperature must be > 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = p->H, Z = p->Z, K = p->K, Hp = p->Hp, Zp = p->Zp, Kp = p->Kp, Ep = p->Ep, E = p->E;
+    const int64_t R = p->R;
+    // caller-supplied gradients replace the records the other phases accumulate (padding columns stay zero)
+    if (d_emb) {
+        float* de = p->wsf("d_emb");
+        SV_CHECK_HIP(hipMemsetAsync(de, 0, (size_t)R * Ep * sizeof(float), s));
+        SV_TRY(launch_copy2d(d_emb, E, 0, H, de, Ep, 0, R, s));
+        SV_TRY(launch_copy2d(d_emb, E, H, K, de, Ep, Hp, R, s));
+        SV_TRY(launch_copy2d(d_emb, E, H + K, H, de, Ep, Hp + Kp, R, s));
+    }
+    if (dmu) SV_TRY(launch_copy2d(dmu, Z, 0, Z, p->wsf("dmu_ext"), Zp, 0, R, s));
+    if (dstd) SV_TRY(launch_copy2d(dstd, Z, 0, Z, p->wsf("dsd_ext"), Zp, 0, R, s));
+    if (dlogits) SV_TRY(launch_copy2d(dlogits, K, 0, K, p->wsf("dlg_kl"), Kp, 0, R, s));
+    return phase_scan_bwd(p, x, u, eps, temp, s);
+}
+
+int shivae_loss_reduce(shivae_plan* p, float beta, float inv_batch, float* losses, shivae_stream stream) {
+    SV_REQUIRE(p && losses, "loss_reduce: null argument");
+    SV_BOUND("loss_reduce");
+    return launch_loss_reduce(p->wsf("rowloss"), p->wsf("persum"), p->T, p->B, beta, inv_batch, losses,
+                              static_cast<hipStream_t>(stream));
+}
+
 int shivae_sample_prior(shivae_plan* p, const float* u, const float* eps, float temp, shivae_stream stream) {
     SV_REQUIRE(p && u && eps, "sample_prior: null argument");
     if (!p->bound) {
@@ -1014,6 +1115,11 @@ int shivae_output_width(const shivae_plan* p, int which) {
         case SHIVAE_O_DEC_PARAMS: return p->P;
         case SHIVAE_O_ROWLOSS: return 6;
         case SHIVAE_O_H_PREV: case SHIVAE_O_PHI_Z: return p->H;
+        case SHIVAE_O_A_S: case SHIVAE_O_E1: case SHIVAE_O_E2: case SHIVAE_O_C_NEW: return p->H;
+        case SHIVAE_O_D_PHIZ_PRE: case SHIVAE_O_D_E2_PRE: case SHIVAE_O_D_E1_PRE: case SHIVAE_O_D_AS_PRE: return p->H;
+        case SHIVAE_O_LOGITS: case SHIVAE_O_D_LOGITS_PRE: return p->K;
+        case SHIVAE_O_D_MU: case SHIVAE_O_D_STD_PRE: return p->Z;
+        case SHIVAE_O_GATES: case SHIVAE_O_D_GATES: return 4 * p->H;
     }
     return 0;
 }
@@ -1037,6 +1143,25 @@ int shivae_get_output(shivae_plan* p, int which, float* dst, shivae_stream strea
         case SHIVAE_O_DEC_PARAMS:
             SV_REQUIRE(p->last_flags & SHIVAE_STEP_KEEP_PARAMS, "get_output: last step did not keep decoder parameters");
             return launch_unpad_copy(p->wsf("pfull"), p->P, 0, p->P, dst, R, s);
+        // records of the recurrent scans (kernel-level parity tests)
+        case SHIVAE_O_A_S: return launch_unpad_copy(p->wsf("as"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_E1: return launch_unpad_copy(p->wsf("e1"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_E2: return launch_unpad_copy(p->wsf("e2"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_C_NEW: return launch_unpad_copy(p->wsf("cnew"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_LOGITS: return launch_unpad_copy(p->wsf("logits"), p->Kp, 0, p->K, dst, R, s);
+        case SHIVAE_O_D_PHIZ_PRE: return launch_unpad_copy(p->wsf("d_phiz_pre"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_D_E2_PRE: return launch_unpad_copy(p->wsf("d_e2_pre"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_D_E1_PRE: return launch_unpad_copy(p->wsf("d_e1_pre"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_D_AS_PRE: return launch_unpad_copy(p->wsf("d_as_pre"), p->Hp, 0, p->H, dst, R, s);
+        case SHIVAE_O_D_LOGITS_PRE: return launch_unpad_copy(p->wsf("d_lg_pre"), p->Kp, 0, p->K, dst, R, s);
+        case SHIVAE_O_D_MU: return launch_unpad_copy(p->wsf("d_mu"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_D_STD_PRE: return launch_unpad_copy(p->wsf("d_sd_pre"), p->Zp, 0, p->Z, dst, R, s);
+        case SHIVAE_O_GATES: case SHIVAE_O_D_GATES: {  // four gate blocks i,f,g,o, each padded H -> Hp in the records
+            const float* src = p->wsf(which == SHIVAE_O_GATES ? "gates" : "d_gates");
+            for (int gt = 0; gt < 4; ++gt)
+                SV_TRY(launch_copy2d(src, 4 * p->Hp, gt * p->Hp, p->H, dst, 4 * p->H, gt * p->H, R, s));
+            return SHIVAE_OK;
+        }
     }
     set_error("get_output: unknown output %d", which);
     return SHIVAE_ERR_INVALID;

@@ -354,10 +354,10 @@ class ShiVAE(nn.Module):
                 o = torch.empty(T, b1 - b0, plan.output_width(w), dtype=torch.float32, device=dev)
                 N.check(L.shivae_get_output(plan.h, w, N.ptr(o), N.stream()))
                 outs[w].append(o)
-            if collect is not None:
-                ps = torch.empty(b1 - b0, 6, dtype=torch.float32, device=dev)
-                N.check(L.shivae_get_persum(plan.h, N.ptr(ps), N.stream()))
-                persum.append(ps)
+            # per-sequence sums over t (base_missvae.py:284,318,343): B x 6 floats, kept for callers and tests
+            ps = torch.empty(b1 - b0, 6, dtype=torch.float32, device=dev)
+            N.check(L.shivae_get_persum(plan.h, N.ptr(ps), N.stream()))
+            persum.append(ps)
         outs = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
         self._last = dict(u=u, eps=eps, persum=torch.cat(persum) if persum else None)
         return losses, outs

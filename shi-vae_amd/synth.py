@@ -13,6 +13,7 @@ def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda"
     the rows a single process would have generated there (seq0 must sit on a block boundary)."""
     assert seq0 % chunk == 0, "a shard starts on a block of %d sequences" % chunk
     g = torch.Generator(device=device)
+    x_is_cuda = torch.device(device).type == "cuda"
     xs, ms = [], []
     for b0 in range(0, B, chunk):
         b = min(chunk, B - b0)
@@ -53,6 +54,10 @@ def synth_batch(types_list, T, B, miss=0.3, n_states=3, seed=1234, device="cuda"
             diff.scatter_add_(0, torch.clamp(start + length, max=T), -torch.ones(nb, b, device=device))
             m = diff.cumsum(0)[:T] > 0
             mcols.append(m.unsqueeze(-1).expand(T, b, dim))
+            if x_is_cuda:
+                # keep the launch queue shallow (a dozen small kernels per attribute, tens of thousands per batch):
+                # `rocprofv3 --pmc` does not survive thousands of dispatches enqueued ahead of the GPU
+                torch.cuda.synchronize()
         x = torch.cat(cols, -1)
         m = torch.cat(mcols, -1)
         xs.append(torch.where(m, torch.zeros_like(x), x))

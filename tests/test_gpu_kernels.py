@@ -209,3 +209,113 @@ def test_clip_adam_kernel():
         torch.cuda.synchronize()
         np.testing.assert_allclose(float(sq.sqrt()), tot, rtol=1e-5)
         np.testing.assert_allclose(pt.cpu().numpy(), P["w"], rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------- the phases of the step (SURVEY.md 8b minimum set)
+def _bound_model(tl, T, B, H, Z, K, P, learn_std=True):
+    import shivae_amd
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=learn_std)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m.zero_grad()
+    return m, m._activate(T, B)
+
+
+def _out(plan, which, T, B):
+    o = torch.empty(T, B, plan.output_width(N.O[which]), device=DEV)
+    N.check(N.lib().shivae_get_output(plan.h, N.O[which], N.ptr(o), N.stream()))
+    torch.cuda.synchronize()
+    return o.cpu().numpy()
+
+
+SCAN_CASES = {
+    # name: (n_real, n_pos, n_bin, cats, T, B, H, Z, K)
+    "h16": (1, 1, 1, [3], 9, 21, 16, 4, 3),
+    "h80_multiwave": (2, 1, 1, [5], 6, 18, 80, 24, 6),
+    "k20_two_ktiles": (2, 1, 1, [3], 5, 17, 32, 6, 20),
+}
+
+
+@pytest.mark.parametrize("name", list(SCAN_CASES))
+def test_scan_fwd_and_bwd_records_match_oracle(name):
+    """shivae_scan_fwd / shivae_scan_bwd on their own: every record of the forward chain (shivae.py:102-143) and of
+    the reverse-time chain against the oracle, the backward driven by the oracle's own incoming gradients."""
+    import shivae_amd
+    nr, npos, nb, cats, T, B, H, Z, K = SCAN_CASES[name]
+    tl = shivae_amd.utils.make_types_list(nr, npos, nb, cats)
+    rng = np.random.default_rng(len(name) * 7 + H)
+    P = so.init_params(tl, H, Z, K, True, seed=3)
+    for k in P:
+        if "bias" in k:
+            P[k] = (rng.standard_normal(P[k].shape) * 0.1).astype(np.float32)
+    X = so.x_dim(tl)
+    x = rng.standard_normal((T, B, X)).astype(np.float32)
+    mask = rng.random((T, B, X)) < 0.3
+    x = np.where(mask, 0, x).astype(np.float32)
+    u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+    temp, beta = 1.3, 0.7
+    om = so.OracleShiVAE(P, tl, H, Z, K, True)
+    c = om.forward(x, mask, u, eps, beta, temp)
+    G = om.backward()
+    m, plan = _bound_model(tl, T, B, H, Z, K, P)
+    xt, ut, et = _t(x), _t(u), _t(eps)
+    L = N.lib()
+    N.check(L.shivae_scan_fwd(plan.h, N.ptr(xt), N.ptr(ut), N.ptr(et), temp, N.stream()))
+    fwd = {"Z": c["z"], "Z_MEAN": c["mu"], "Z_STD": c["std"], "S": c["s"], "S_PROBS": c["probs"], "PHI_Z": c["phi_z"],
+           "H_PREV": c["h_prev"], "A_S": c["a_s"], "LOGITS": c["logits"], "E1": c["e1"], "E2": c["e2"],
+           "C_NEW": c["c_new"], "GATES": np.concatenate([c["gi"], c["gf"], c["gg"], c["go"]], -1)}
+    for k, ref in fwd.items():
+        np.testing.assert_allclose(_out(plan, k, T, B), ref, rtol=1e-4, atol=2e-5, err_msg=k)
+    # the gradients that reach the chain from the decoder, the prior and the KL terms, as the oracle has them
+    sb = c["scan_bwd"]
+    d_emb = np.concatenate([sb["dphi_z_ext"], sb["ds_ext"], sb["dh_ext"]], -1)
+    pb, dpr = c["probs"], sb["dprobs"]
+    dlg_ext = pb * (dpr - (pb * dpr).sum(-1, keepdims=True))
+    ext = [_t(a) for a in (d_emb, sb["dmu_ext"], sb["dstd_ext"], dlg_ext)]
+    N.check(L.shivae_scan_bwd(plan.h, N.ptr(xt), N.ptr(ut), N.ptr(et), temp, *[N.ptr(a) for a in ext], N.stream()))
+    bwd = {"D_GATES": sb["d_gates"], "D_PHIZ_PRE": sb["d_phiz_pre"], "D_MU": sb["d_mu"], "D_STD_PRE": sb["d_std_pre"],
+           "D_E2_PRE": sb["d_e2_pre"], "D_E1_PRE": sb["d_e1_pre"], "D_LOGITS_PRE": sb["d_lg_pre"], "D_AS_PRE": sb["d_as_pre"]}
+    for k, ref in bwd.items():
+        got = _out(plan, k, T, B)
+        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    # ... and the parameter gradients this phase owns (the recurrent cell, the encoder, phi_x)
+    m._publish_grads(None)
+    for k, p in m.named_parameters():
+        if k.startswith(("encoder.", "phi_z.", "rnn.")):
+            err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
+            assert err < 5e-4, (k, err)
+
+
+def test_phases_compose_to_the_step():
+    """shivae_elbo_step == scan_fwd; prior_kl; decoder_nll; scan_bwd; loss_reduce (same kernels, same order)."""
+    import shivae_amd
+    tl = shivae_amd.utils.make_types_list(2, 2, 1, [3, 4])
+    T, B, H, Z, K = 7, 26, 32, 8, 5
+    rng = np.random.default_rng(21)
+    P = so.init_params(tl, H, Z, K, True, seed=4)
+    X = so.x_dim(tl)
+    x = rng.standard_normal((T, B, X)).astype(np.float32)
+    mask = rng.random((T, B, X)) < 0.4
+    mask[..., 5:8] = mask[..., 5:6]; mask[..., 8:12] = mask[..., 8:9]
+    x = np.where(mask, 0, x).astype(np.float32)
+    u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+    xt, mt, ut, et = _t(x), torch.as_tensor(mask, device=DEV).view(torch.uint8), _t(u), _t(eps)
+    beta, temp, ib = 0.6, 2.0, 1.0 / B
+    L = N.lib()
+    res = []
+    for composed in (False, True):
+        m, plan = _bound_model(tl, T, B, H, Z, K, P)
+        losses = torch.zeros(16, device=DEV)
+        s = N.stream()
+        if not composed:
+            N.check(L.shivae_elbo_step(plan.h, N.ptr(xt), N.ptr(mt), N.ptr(ut), N.ptr(et), beta, temp, ib, 0, N.ptr(losses), s))
+        else:
+            N.check(L.shivae_scan_fwd(plan.h, N.ptr(xt), N.ptr(ut), N.ptr(et), temp, s))
+            N.check(L.shivae_prior_kl(plan.h, beta, ib, 0, s))
+            N.check(L.shivae_decoder_nll(plan.h, N.ptr(xt), N.ptr(mt), ib, 0, s))
+            N.check(L.shivae_scan_bwd(plan.h, N.ptr(xt), N.ptr(ut), N.ptr(et), temp, None, None, None, None, s))
+            N.check(L.shivae_loss_reduce(plan.h, beta, ib, N.ptr(losses), s))
+        torch.cuda.synchronize()
+        res.append((losses[:9].cpu().numpy(), m.flat_grads.cpu().numpy().copy()))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-6)
+    assert np.abs(res[1][1] - res[0][1]).max() <= 1e-5 * np.abs(res[0][1]).max()  # (atomic summation order)
+    assert np.abs(res[0][1]).max() > 0

@@ -60,9 +60,32 @@ def test_losses_and_gradients_match_reference(name):
         assert p.grad is not None, k
         err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
         assert err < GRAD_RTOL, (k, err)
-    # per-sequence sums (base_missvae.py:284,318,343)
-    ps = m._last["persum"]
-    assert ps is None or True
+    # per-sequence sums over t of the six terms (base_missvae.py:284,318,343)
+    ps = m._last["persum"].cpu().numpy()
+    assert ps.shape == (cfg["B"], 6)
+    for i, ty in enumerate(("real", "pos", "bin", "cat")):
+        np.testing.assert_allclose(ps[:, i], g["nll_b/nll_" + ty], rtol=1e-4, atol=2e-4, err_msg=ty)
+    np.testing.assert_allclose(ps[:, 4], g["klz_b"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ps[:, 5], g["kls_b"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_fused_clip_adam_on_golden_gradients(name):
+    """trainers.py:222-224 clip_grad_norm_(0.5) + Adam(lr=5e-3).step() on the reference's own gradients: the HIP
+    optimiser alone (gradient buffer filled from the golden vectors), then compared with the reference's
+    parameters after that step and its total gradient norm."""
+    g, cfg, sd = _golden.load(name)
+    m = _model(cfg, sd)
+    opt = shivae_amd.FusedClipAdam(m, lr=5e-3, clip=0.5)
+    opt.zero_grad()
+    for k, p in m.named_parameters():
+        p.grad.copy_(torch.from_numpy(g["grad/" + k]))  # views of the flat gradient buffer
+    opt.step()
+    np.testing.assert_allclose(float(opt.last_grad_sqnorm.sqrt()), g["grad_norm"], rtol=1e-5)
+    for k, p in m.named_parameters():
+        # compare the UPDATE (parameters move by about lr = 5e-3 per element)
+        upd, ref = p.detach().cpu().numpy() - sd[k], g["adam1/" + k] - sd[k]
+        assert np.abs(upd - ref).max() <= 2e-6, (k, np.abs(upd - ref).max())
 
 
 @pytest.mark.parametrize("name", ["cfg1_T100_B8", "tiny_all"])

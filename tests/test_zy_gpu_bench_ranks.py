@@ -33,3 +33,79 @@ def test_two_ranks_on_one_gpu():
     assert j["config"]["global_batch"] == 16 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["n_elbo"] == j["n_elbo"]  # finite
     assert j["roofline"] is not None and "cpu_baseline" not in j
+
+
+_DP_SCRIPT = r'''
+import os, sys, tempfile, types
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import shivae_amd
+from test_gpu_step import _synth
+
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+tl = shivae_amd.utils.make_types_list(2, 1, 1, [3, 5])
+T, B, H, Z, K = 12, 32, 24, 6, 4
+rng = np.random.default_rng(11)          # the SAME global batch and noise on every rank
+x, mask = _synth(rng, tl, T, B, 0.3)
+u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+xt, mt = torch.from_numpy(x).cuda(), torch.from_numpy(mask).cuda()
+torch.manual_seed(0)
+m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+m.train()
+p0 = m.flat_params.clone()
+
+# single-process step on the global batch (trainers.py:209-224)
+opt = shivae_amd.FusedClipAdam(m, lr=5e-3, clip=0.5)
+opt.zero_grad()
+m.set_noise(u, eps)
+m(xt, mt, beta=1.0, temp=3)["n_elbo"].backward()
+g_ref = m.flat_grads.clone()
+opt.step()
+p_ref = m.flat_params.clone()
+
+# the same step data-parallel: rank r takes rows [r*B/w, (r+1)*B/w) of x, mask, u, eps (SURVEY.md 8e)
+sl = slice(r * B // w, (r + 1) * B // w)
+m.flat_params.copy_(p0)
+opt = shivae_amd.FusedClipAdam(m, lr=5e-3, clip=0.5)
+opt.zero_grad()
+m.set_noise(u[:, sl], eps[:, sl])
+m(xt[:, sl], mt[:, sl], beta=1.0, temp=3, inv_batch=1.0 / B)["n_elbo"].backward()
+m.allreduce_grads()
+eg = float((m.flat_grads - g_ref).abs().max() / g_ref.abs().max())
+opt.step()
+ep = float((m.flat_params - p_ref).abs().max())
+assert eg < 1e-4, ("all-reduced gradient", eg)
+assert ep < 1e-4, ("parameters after clip+Adam", ep)
+
+# and through Trainer.train_epoch, which has to find 1/B_global by itself
+m.flat_params.copy_(p0)
+args = types.SimpleNamespace(l_rate=5e-3, n_epochs=1, kl_annealing_epochs=0, clip=0.5, save_every=100, print_every=100,
+                             save_model=False, result_dir=tempfile.mkdtemp(prefix="shivae_dp%%d_" %% r), restore=False)
+tr = shivae_amd.Trainer(m, shivae_amd.FusedClipAdam(m, lr=5e-3), args)
+m.set_noise(u[:, sl], eps[:, sl])
+shard = (np.ascontiguousarray(x[:, sl].transpose(1, 0, 2)), np.ascontiguousarray(mask[:, sl].transpose(1, 0, 2)), None)
+logged = tr.train_epoch([shard], 1)
+et = float((m.flat_params - p_ref).abs().max())
+assert et < 1e-4, ("Trainer.train_epoch under data parallel", et)
+single = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+single.flat_params.copy_(p0); single.eval(); single.set_noise(u, eps)
+ref_loss = float(single(xt, mt, beta=1.0, temp=3)["n_elbo"])
+assert abs(logged["n_elbo"] - ref_loss) < 1e-4 * abs(ref_loss), (logged["n_elbo"], ref_loss)
+print("rank %%d ok: grad %%.2e params %%.2e trainer %%.2e" %% (r, eg, ep, et), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    """Sharded + all-reduced gradients and the parameters after clip+Adam equal the single-process step on the same
+    global batch (SURVEY.md 8e partitioning), directly and through Trainer.train_epoch."""
+    script = tmp_path / "dp_check.py"
+    script.write_text(_DP_SCRIPT % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count(" ok: ") == 2, r.stdout[-1500:]
