@@ -236,6 +236,13 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
 int shivae_zero(float* buf_dev, int64_t n, shivae_stream stream);
 /* sum of squares of a flat buffer -> *out_dev (overwritten); scratch_dev: >= 1024 floats */
 int shivae_sqnorm(const float* buf_dev, int64_t n, float* scratch_dev, float* out_dev, shivae_stream stream);
+/* shivae_sqnorm for callers that cannot allocate or pass a scratch buffer (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The block partials live in
+ * a 4 KiB file-scope device array that every GPU the library runs on holds until the process ends; the entry point
+ * calls no hipMalloc / hipFree.  n is limited to SHIVAE_SQNORM_NOALLOC_MAX elements (larger n is rejected).  All
+ * calls on one GPU share that array: calls that overlap on one GPU (two streams) race -- serialise them. */
+#define SHIVAE_SQNORM_NOALLOC_MAX ((int64_t)1 << 32)
+int shivae_sqnorm_noalloc(const float* buf_dev, int64_t n, float* out_dev, shivae_stream stream);
 /* torch.nn.utils.clip_grad_norm_(params, clip) followed by torch.optim.Adam.step()
  * (trainers.py:222-224) on flat buffers; sqnorm_dev holds the squared global gradient norm
  * (after any all-reduce).  step is the 1-based Adam step count. */

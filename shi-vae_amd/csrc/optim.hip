@@ -140,6 +140,27 @@ int launch_sqnorm(const float* buf, int64_t n, float* scratch, float* out, hipSt
     return SHIVAE_OK;
 }
 
+// ---- the same reduction for callers that cannot allocate (shivae_sqnorm_noalloc): the block partials live in a
+// file-scope device array instead of a caller-provided buffer.  Every GPU holds its own copy of the array at its
+// own address; the host-side name is only a handle for hipGetSymbolAddress, never a kernel argument.
+static __device__ __align__(256) float scratch[1024];
+static constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+int launch_sqnorm_noalloc(const float* buf, int64_t n, float* out, hipStream_t stream) {
+    int dev = -1;
+    SV_CHECK_HIP(hipGetDevice(&dev));
+    SV_REQUIRE(dev >= 0 && dev < kMaxDevices, "sqnorm_noalloc: device ordinal %d out of range", dev);
+    if (!g_scratch_ptr[dev]) {  // first call on this device (with it current): resolve this device's copy once
+        void* ptr = nullptr;
+        SV_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        SV_REQUIRE(ptr != nullptr, "sqnorm_noalloc: no device address for the scratch array");
+        g_scratch_ptr[dev] = static_cast<float*>(ptr);
+    }
+    // all `parts` partials are overwritten before the final kernel reads them: nothing has to start at zero
+    return launch_sqnorm(buf, n, g_scratch_ptr[dev], out, stream);
+}
+
 // clip coefficient = min(clip / (norm + 1e-6), 1)  (torch clip_grad_norm_), then Adam (no weight
 // decay, no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -1298,6 +1298,13 @@ int shivae_sqnorm(const float* buf, int64_t n, float* scratch, float* out, shiva
     return launch_sqnorm(buf, n, scratch, out, static_cast<hipStream_t>(stream));
 }
 
+int shivae_sqnorm_noalloc(const float* buf, int64_t n, float* out, shivae_stream stream) {
+    SV_REQUIRE(buf && out && n >= 0, "sqnorm_noalloc: bad argument");
+    SV_REQUIRE(n <= SHIVAE_SQNORM_NOALLOC_MAX, "sqnorm_noalloc: %lld elements exceed the supported maximum of %lld",
+               (long long)n, (long long)SHIVAE_SQNORM_NOALLOC_MAX);
+    return launch_sqnorm_noalloc(buf, n, out, static_cast<hipStream_t>(stream));
+}
+
 int shivae_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sqnorm, float clip,
                      float lr, float b1, float b2, float eps, int step, shivae_stream stream) {
     SV_REQUIRE(params && grads && m && v && sqnorm, "clip_adam: null argument");
