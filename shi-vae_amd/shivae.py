@@ -579,6 +579,6 @@ class ShiVAE(nn.Module):
             # RCCL orders itself behind the step's kernels on the current stream: no host wait.  gloo (CPU / 1-GPU
             # rehearsals) stages device tensors through the host from its own threads, so there the host waits for
             # the step first.
-            if self._gflat.is_cuda and dist.get_backend() != "nccl":
+            if self._gflat.is_cuda and dist.get_backend() != "nccl" and not os.environ.get("SHIVAE_GLOO_NO_WAIT"):
                 torch.cuda.current_stream().synchronize()
             dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)
