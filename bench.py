@@ -171,6 +171,7 @@ def main():
     torch.manual_seed(0)  # same replica on every rank (reference init scheme, seed 0)
     model = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
     model.check_nan = False
+    model.overlap_allreduce = True  # N > 1: the decoder's gradient buckets start before the reverse-time scan
     model.train()
     opt = shivae_amd.FusedClipAdam(model, lr=5e-3, clip=0.5)
     # one global batch (seed 1234), sharded by sequence: blocks of `blk` sequences have their own generator streams
@@ -184,6 +185,9 @@ def main():
         % (a.config, B, Bl, micro, T, sum(p.numel() for p in model.parameters())))
 
     trace = os.environ.get("SHIVAE_BENCH_TRACE") is not None
+    if trace and os.environ["SHIVAE_BENCH_TRACE"].startswith("dump"):  # e.g. dump40: all Python stacks after 40 s
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SHIVAE_BENCH_TRACE"][4:] or 40), exit=False)
 
     def tr(msg):
         if trace:

@@ -250,6 +250,18 @@ int shivae_clip_adam(float* params_dev, const float* grads_dev, float* exp_avg_d
                      int64_t n, const float* sqnorm_dev, float clip, float lr, float beta1, float beta2,
                      float eps, int step, shivae_stream stream);
 
+/* ---- data parallel (no counterpart in the reference, which is single-process) ----------------
+ * Sum the flat gradient buffer over the ranks of an RCCL communicator, in place, in buckets of bucket_floats
+ * (<= 0: one message), enqueued on `stream`: call it after the step on the step's stream, BEFORE
+ * shivae_sqnorm / shivae_clip_adam (the global norm of trainers.py:222 is the norm of the summed gradient; every
+ * rank ran its shard with inv_batch = 1/B_global).  rccl_comm is an ncclComm_t: the caller's own, or one made by
+ * shivae_comm_init from the 128-byte id that rank 0 got from shivae_comm_unique_id and sent to the other ranks.
+ * librccl is opened at the first of these calls (dlopen), not at load time. */
+int shivae_comm_unique_id(void* id128_out);
+int shivae_comm_init(void** rccl_comm_out, int world_size, int rank, const void* id128);
+int shivae_comm_destroy(void* rccl_comm);
+int shivae_allreduce_grads(float* grads_dev, int64_t n, void* rccl_comm, int64_t bucket_floats, shivae_stream stream);
+
 /* ---- pre/post pass either side of the step ---------------------------- */
 /* One attribute of a fitted HeterogeneousScaler (lib/scalers.py:27-58): type, first one-hot/x column
  * (utils.get_idx_transform, lib/utils.py:291-315), x columns (1, or nclass for cat), raw column

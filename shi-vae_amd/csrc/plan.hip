@@ -14,6 +14,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is looked up at run time (see rccl_api)
+
 #include "common.h"
 
 namespace shivae {
@@ -1303,6 +1306,100 @@ int shivae_sqnorm_noalloc(const float* buf, int64_t n, float* out, shivae_stream
     SV_REQUIRE(n <= SHIVAE_SQNORM_NOALLOC_MAX, "sqnorm_noalloc: %lld elements exceed the supported maximum of %lld",
                (long long)n, (long long)SHIVAE_SQNORM_NOALLOC_MAX);
     return launch_sqnorm_noalloc(buf, n, out, static_cast<hipStream_t>(stream));
+}
+
+// ---- gradient all-reduce over an RCCL communicator.  librccl is not a link-time dependency: it is
+// opened on first use, so that single-GPU users never load it and a process that already holds an RCCL (torch's)
+// shares that copy.
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static int rccl_api(const RcclApi** out) {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.handle, "ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        }
+    }
+    if (!api.handle || !api.AllReduce || !api.GroupStart || !api.GroupEnd || !api.GetUniqueId || !api.CommInitRank ||
+        !api.CommDestroy || !api.GetErrorString) {
+        set_error("RCCL not available: %s", api.handle ? "librccl lacks a required symbol" : dlerror());
+        return SHIVAE_ERR_HIP;
+    }
+    *out = &api;
+    return SHIVAE_OK;
+}
+#define SV_CHECK_RCCL(api, expr)                                                                  \
+    do {                                                                                          \
+        ncclResult_t r__ = (expr);                                                                \
+        if (r__ != ncclSuccess) {                                                                 \
+            set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, (api)->GetErrorString(r__));   \
+            return SHIVAE_ERR_HIP;                                                                \
+        }                                                                                         \
+    } while (0)
+
+int shivae_comm_unique_id(void* id_out) {
+    SV_REQUIRE(id_out, "comm_unique_id: null argument");
+    const RcclApi* api;
+    SV_TRY(rccl_api(&api));
+    ncclUniqueId id;
+    SV_CHECK_RCCL(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return SHIVAE_OK;
+}
+
+int shivae_comm_init(void** comm_out, int world, int rank, const void* id_in) {
+    SV_REQUIRE(comm_out && id_in && world >= 1 && rank >= 0 && rank < world, "comm_init: bad argument");
+    const RcclApi* api;
+    SV_TRY(rccl_api(&api));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    ncclComm_t c = nullptr;
+    SV_CHECK_RCCL(api, api->CommInitRank(&c, world, id, rank));
+    *comm_out = c;
+    return SHIVAE_OK;
+}
+
+int shivae_comm_destroy(void* comm) {
+    if (!comm) return SHIVAE_OK;
+    const RcclApi* api;
+    SV_TRY(rccl_api(&api));
+    SV_CHECK_RCCL(api, api->CommDestroy(static_cast<ncclComm_t>(comm)));
+    return SHIVAE_OK;
+}
+
+int shivae_allreduce_grads(float* grads, int64_t n, void* comm, int64_t bucket_floats, shivae_stream stream) {
+    SV_REQUIRE(grads && comm && n >= 0, "allreduce_grads: bad argument");
+    const RcclApi* api;
+    SV_TRY(rccl_api(&api));
+    const int64_t b = bucket_floats > 0 ? bucket_floats : n;
+    // one group of in-place sums, bucket by bucket: ring collectives over xGMI are bound per link, and buckets of
+    // ~100 MB keep every link streaming while staying small enough to pipeline
+    SV_CHECK_RCCL(api, api->GroupStart());
+    for (int64_t a = 0; a < n; a += b)
+        SV_CHECK_RCCL(api, api->AllReduce(grads + a, grads + a, (size_t)std::min<int64_t>(b, n - a), ncclFloat, ncclSum,
+                                          static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)));
+    SV_CHECK_RCCL(api, api->GroupEnd());
+    return SHIVAE_OK;
 }
 
 int shivae_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, const float* sqnorm, float clip,

@@ -80,6 +80,12 @@ class ShiVAE(nn.Module):
         self.check_nan = True       # base_missvae.py:223-228 (one host sync per forward)
         self.workspace_limit_bytes = int(float(os.environ.get("SHIVAE_WS_GB", "0")) * 1e9) or None
         self.chunk_rows = int(os.environ.get("SHIVAE_CHUNK_ROWS", "0"))
+        # data parallel: start the all-reduce of the decoder's gradients (99 % of the buffer) as soon as the last
+        # decoder row chunk is done, in buckets, while the reverse-time scan and the cell's weight gradients still
+        # run.  Opt-in, because the caller then HAS to call allreduce_grads() (bench.py and Trainer do).
+        self.overlap_allreduce = False
+        self.bucket_floats = int(float(os.environ.get("SHIVAE_BUCKET_MB", "128")) * (1 << 18))
+        self._pending_reduce = []
         self._pending_noise = None
         self._plans = {}
         self._chunk_done = set()
@@ -214,6 +220,9 @@ class ShiVAE(nn.Module):
 
     def _publish_grads(self, go=None):
         fresh = self._slices[0][0].grad is None
+        if go is not None and fresh and self._pending_reduce:
+            for w in self._pending_reduce[0][1]:  # (the scaling below must not race with buckets in flight)
+                w.wait()
         if go is not None and fresh:
             self._gflat.mul_(go.reshape(()))
         for p, off, n, shape in self._slices:
@@ -348,8 +357,19 @@ class ShiVAE(nn.Module):
             else:
                 xs, ms = x[:, b0:b1].contiguous(), mask[:, b0:b1].contiguous()
                 us, es = u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous()
-            N.check(L.shivae_elbo_step(plan.h, N.ptr(xs), N.ptr(ms.view(torch.uint8)), N.ptr(us), N.ptr(es),
-                                       float(beta), float(temp), inv_batch, flags, N.ptr(losses), N.stream()))
+            if grad and b1 == B and self.overlap_allreduce and self._dp_backend() == "nccl":
+                # last micro-batch of a data-parallel step, phase by phase (== shivae_elbo_step): the decoder's
+                # gradients are final once its last row chunk is done
+                st, m8 = N.stream(), ms.view(torch.uint8)
+                N.check(L.shivae_scan_fwd(plan.h, N.ptr(xs), N.ptr(us), N.ptr(es), float(temp), st))
+                N.check(L.shivae_prior_kl(plan.h, float(beta), inv_batch, flags, st))
+                N.check(L.shivae_decoder_nll(plan.h, N.ptr(xs), N.ptr(m8), inv_batch, flags, st))
+                self._start_bucket_allreduce()
+                N.check(L.shivae_scan_bwd(plan.h, N.ptr(xs), N.ptr(us), N.ptr(es), float(temp), None, None, None, None, st))
+                N.check(L.shivae_loss_reduce(plan.h, float(beta), inv_batch, N.ptr(losses), st))
+            else:
+                N.check(L.shivae_elbo_step(plan.h, N.ptr(xs), N.ptr(ms.view(torch.uint8)), N.ptr(us), N.ptr(es),
+                                           float(beta), float(temp), inv_batch, flags, N.ptr(losses), N.stream()))
             for w in outs:
                 o = torch.empty(T, b1 - b0, plan.output_width(w), dtype=torch.float32, device=dev)
                 N.check(L.shivae_get_output(plan.h, w, N.ptr(o), N.stream()))
@@ -571,14 +591,45 @@ class ShiVAE(nn.Module):
         return (likes, self.generate_heter_samples(likes)), z_prior_tup, s_tup
 
     # ------------------------------------------------------------------ data parallel
+    def _dp_backend(self):
+        """Backend name if a process group with more than one rank is up (SHIVAE_FORCE_DP=1: also with one), else None."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SHIVAE_FORCE_DP")):
+            return dist.get_backend()
+        return None
+
+    def _start_bucket_allreduce(self):
+        """Asynchronous RCCL all-reduce of the decoder's part of the flat gradient buffer, bucket by bucket.  RCCL's
+        stream orders itself behind the kernels already enqueued on the current stream (the decoder phase), and the
+        kernels enqueued after this call (reverse-time scan, cell gradients) overlap with the collective: they write
+        the front of the buffer only."""
+        import torch.distributed as dist
+        off = self._layout.param_info(N.P["DEC0_W"], 0)[0]  # the decoder tensors are the tail of the layout
+        n, b = self._n_flat, max(1, self.bucket_floats)
+        self._pending_reduce = [(off, [dist.all_reduce(self._gflat[a:min(a + b, n)], op=dist.ReduceOp.SUM, async_op=True)
+                                       for a in range(off, n, b)])]
+
     def allreduce_grads(self):
         """Sum the flat gradient buffer over the ranks (RCCL all-reduce over xGMI).  Each rank ran its
         batch shard with inv_batch = 1/B_global, so the sum IS the global-batch gradient."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # RCCL orders itself behind the step's kernels on the current stream: no host wait.  gloo (CPU / 1-GPU
-            # rehearsals) stages device tensors through the host from its own threads, so there the host waits for
-            # the step first.
-            if self._gflat.is_cuda and dist.get_backend() != "nccl" and not os.environ.get("SHIVAE_GLOO_NO_WAIT"):
-                torch.cuda.current_stream().synchronize()
+        backend = self._dp_backend()
+        if backend is None:
+            return
+        if self._pending_reduce:  # the decoder's buckets are in flight: reduce the rest, then join them
+            (off, works), = self._pending_reduce
+            self._pending_reduce = []
+            dist.all_reduce(self._gflat[:off], op=dist.ReduceOp.SUM)
+            for w in works:
+                w.wait()
+        elif backend == "nccl" or not self._gflat.is_cuda:
+            # RCCL orders itself behind the step's kernels on the current stream: no host wait
             dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)
+        else:
+            # gloo (CPU / 1-GPU rehearsals of the N>1 path): staged through the host by hand.  torch's gloo backend
+            # handed a DEVICE tensor while the step's kernels are still in flight was seen to block both ranks
+            # inside all_reduce for good (two ranks sharing one GPU; DESIGN.md s.5); the blocking copy below is
+            # also the wait for the step.
+            host = self._gflat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self._gflat.copy_(host)

@@ -149,6 +149,7 @@ class Trainer:
         epoch_loss, _ = self.init_loss_dict()
         beta = self.annealing_weight.update_beta(epoch)
         self.model.train()
+        self.model.overlap_allreduce = True  # (this loop calls allreduce_grads() after every backward)
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         for data, mask, _attrs in train_loader:

@@ -109,3 +109,70 @@ def test_two_ranks_match_single_process(tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count(" ok: ") == 2, r.stdout[-1500:]
+
+
+_OVERLAP_SCRIPT = r'''
+import os, sys, ctypes
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import shivae_amd
+from shivae_amd import _native as N
+from test_gpu_step import _synth
+
+os.environ["SHIVAE_FORCE_DP"] = "1"           # take the data-parallel code path with one rank
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+tl = shivae_amd.utils.make_types_list(2, 1, 1, [3, 5])
+T, B, H, Z, K = 10, 40, 24, 6, 4
+rng = np.random.default_rng(3)
+x, mask = _synth(rng, tl, T, B, 0.3)
+u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+res = []
+for overlap, micro in ((False, 0), (True, 0), (True, 16)):
+    torch.manual_seed(0)
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+    m.train()
+    m.overlap_allreduce = overlap
+    m.bucket_floats = 1000                     # several buckets
+    if micro:
+        m.micro_batch = lambda T_, B_: micro
+    m.zero_grad()
+    m.set_noise(u, eps)
+    loss = m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.9, temp=2.0)
+    assert bool(m._pending_reduce) == overlap
+    loss["n_elbo"].backward()
+    m.allreduce_grads()
+    assert not m._pending_reduce
+    torch.cuda.synchronize()
+    res.append((float(loss["n_elbo"]), m.flat_grads.clone()))
+for l, g in res[1:]:
+    assert abs(l - res[0][0]) < 1e-5 * abs(res[0][0]), (l, res[0][0])
+    assert float((g - res[0][1]).abs().max()) < 1e-4 * float(res[0][1].abs().max())
+
+# the C-ABI all-reduce on a communicator of its own (one rank: the sum is the buffer itself)
+L = N.lib()
+uid = ctypes.create_string_buffer(128)
+N.check(L.shivae_comm_unique_id(uid))
+comm = ctypes.c_void_p()
+N.check(L.shivae_comm_init(ctypes.byref(comm), 1, 0, uid))
+g = torch.randn(100003, device="cuda")
+g0 = g.clone()
+N.check(L.shivae_allreduce_grads(N.ptr(g), g.numel(), comm, 30000, N.stream()))
+torch.cuda.synchronize()
+assert torch.equal(g, g0)
+N.check(L.shivae_comm_destroy(comm))
+dist.destroy_process_group()
+print("overlap ok", flush=True)
+'''
+
+
+def test_bucketed_allreduce_path_single_rank_rccl(tmp_path):
+    """The overlapped, bucketed gradient all-reduce (phases of the step + async RCCL buckets + the small remainder)
+    gives the gradients of the plain step; and shivae_allreduce_grads runs on an RCCL communicator made through the
+    C ABI.  One rank only: this box has one GPU, and RCCL refuses two ranks on one device."""
+    script = tmp_path / "overlap_check.py"
+    script.write_text(_OVERLAP_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "overlap ok" in r.stdout
