@@ -188,7 +188,8 @@ def profile_name(i):
     i = int(i)
     if i < 18:
         return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 6], _TILES[i % 6])
-    return {18: "scan_fwd_kernel", 19: "scan_bwd_kernel", 20: "heter_nll_kernel", 21: "kl_kernel"}[i]
+    return {18: "scan_fwd_kernel", 19: "scan_bwd_kernel", 20: "heter_nll_kernel", 21: "kl_kernel", 22: "head_fwd_kernel",
+            23: "head_bwd_kernel"}[i]
 
 
 def profile_start():

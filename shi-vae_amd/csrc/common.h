@@ -35,7 +35,7 @@ void set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
 // ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x256)
-enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_COUNT = 22 };
+enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_COUNT = 24 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);
 void prof_shape(int M, int N, int K, int G);  // optional detail for the next prof_begin
@@ -104,6 +104,24 @@ struct ColsumGroup {
 };
 int launch_colsum(int M, int N, int ld, const ColsumGroup* groups_dev, int ngroups,
                   const ColsumGroup& g0, hipStream_t stream);
+
+// ---------------------------------------------------------------- likelihood-parameter heads (heads.hip)
+// One attribute's head Linear(H -> nout): streaming kernels for nout <= 8 (no MFMA).
+struct HeadGroup {
+    const float* hin;   // head input [rows][ldin] (a2 for real/pos, the hidden head layer for bin/cat)
+    float* dhin;        // its gradient (backward), same layout
+    const float* W;     // [nout][H]
+    const float* b;     // [nout]
+    float* gW;          // += weight gradient
+    float* gb;          // += bias gradient
+    float* gprev;       // [H] += column sums of dhin = bias gradient of the layer that produced hin
+    float* P;           // this attribute's columns of the parameter rows [.][ldp]: outputs, then their gradients
+    const int* cnt;     // live rows (mask-aware decoder) or null
+    const int* idx;     // row i of hin belongs to parameter row idx[i], or null
+};
+bool head_kernels_fit(int H, int nout, int ldin, int ldp);
+int launch_heads(bool bwd, const HeadGroup* groups_dev, int ngroups, int nout, int H, int ldin, int ldp, int rows,
+                 bool use_cnt, bool use_idx, hipStream_t stream);
 
 struct AttrDesc;
 // Row lists of the mask-aware decoder: for every attribute d, idx[d*ld_idx + i] = i-th row (ascending) of the

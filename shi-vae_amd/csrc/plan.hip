@@ -78,6 +78,11 @@ struct ColTable {
     ColsumGroup* dev = nullptr;
     int n = 0;
 };
+struct HeadTable {
+    HeadGroup* dev = nullptr;
+    int n = 0;
+    std::vector<int> attr;
+};
 
 }  // namespace shivae
 
@@ -122,6 +127,8 @@ struct shivae_plan {
     int compact = 1;  // mask-aware decoder in training steps (SHIVAE_COMPACT=0: dense)
     std::map<int, GroupTable> f_out, b_out_w, b_out_d;  // keyed by nout
     std::map<int, ColTable> c_out;
+    std::map<int, HeadTable> h_out;  // the same heads for the streaming kernels of heads.hip (nout <= 8)
+    int stream_heads = 1;            // SHIVAE_HEADS=gemm: heads through the grouped GEMMs (comparison runs)
 
     float* wsf(const char* name) const { return reinterpret_cast<float*>(ws + ws_off.at(name)); }
     float* prm(const Tensor& t) const { return params + t.off; }
@@ -373,6 +380,7 @@ static int build_tables(shivae_plan* p) {
     std::map<int, std::vector<GemmGroup>> fo, wo, dO;
     std::map<int, std::vector<int>> ko;
     std::map<int, std::vector<ColsumGroup>> co;
+    std::map<int, std::vector<HeadGroup>> ho;
     for (int d = 0; d < D; ++d) {
         const AttrDesc& a = p->attrs[d];
         const int* cnt = rowcnt + d;
@@ -426,6 +434,7 @@ static int build_tables(shivae_plan* p) {
         wo[key].push_back(G(pd, hin, gwout, nullptr, nullptr, nullptr, list));
         co[key].push_back({pd, gbout});
         dO[key].push_back(G(pd, wout, dhin, nullptr, hmask, dhbias, list));
+        ho[key].push_back(HeadGroup{hin, dhin, wout, bout, gwout, gbout, dhbias, pd, cnt, list});
     }
     SV_TRY(make_table(p, fl0, p->f_l0, all));
     SV_TRY(make_table(p, wl0, p->b_l0_w, all)); SV_TRY(make_table(p, wl0r, p->b_l0_wr, all));
@@ -437,6 +446,12 @@ static int build_tables(shivae_plan* p) {
     for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first], ko[kv.first]));
     for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first], ko[kv.first]));
     for (auto& kv : co) SV_TRY(make_ctable(p, kv.second, p->c_out[kv.first]));
+    for (auto& kv : ho) {
+        HeadTable& t = p->h_out[kv.first];
+        t.n = (int)kv.second.size();
+        t.attr = ko[kv.first];
+        SV_TRY(upload(p, kv.second, &t.dev));
+    }
     return SHIVAE_OK;
 }
 
@@ -522,6 +537,16 @@ static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int
     }
     if ((ragged & RAG_CNT) && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, layout == GEMM_TN ? K : M);
     return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
+}
+// streaming heads (heads.hip) with their profile record: algorithmic bytes = one read of the head input (+ one
+// write of its gradient in the backward) + the parameter columns
+static int heads(bool bwd, const HeadTable& t, int nout, int H, int ldin, int ldp, int rows, bool rag, hipStream_t s) {
+    if (t.n == 0) return SHIVAE_OK;
+    if (rag && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, rows);
+    prof_begin(bwd ? PROF_HEADS_BWD : PROF_HEADS_FWD, (double)t.n * rows * 4.0 * ((bwd ? 2.0 : 1.0) * H + nout), s);
+    SV_TRY(launch_heads(bwd, t.dev, t.n, nout, H, ldin, ldp, rows, rag, rag, s));
+    prof_end(s);
+    return SHIVAE_OK;
 }
 static int colsum1(int M, int N, int ld, const float* Y, float* out, hipStream_t s) {
     return launch_colsum(M, N, ld, nullptr, 1, ColsumGroup{Y, out}, s);
@@ -706,7 +731,12 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             const int key = kv.first, nout = key < 0 ? -key : key;
             // (ragged: stored through the row list, so pbuf stays in chunk-row order; the rows of missing entries
             // keep finite leftovers -- zeros or older parameters -- which the likelihood kernel masks out)
-            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
+            const int ldin = key < 0 ? ldA1 : ldHH;
+            if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
+                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rc, rag, s));
+                continue;
+            }
+            SV_TRY(gemmg(NT, rc, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
         }
         if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
                                               hipMemcpyDeviceToDevice, s));
@@ -720,6 +750,12 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         // ---- decoder backward (pbuf now holds d nll / d head outputs) ----
         for (auto& kv : p->b_out_w) {
             const int key = kv.first, nout = key < 0 ? -key : key, ldin = key < 0 ? ldA1 : ldHH;
+            if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
+                // one streaming pass: input gradient (ReLU-gated), weight and bias gradients, and the bias
+                // gradient of the layer that produced the head input (heads.hip)
+                SV_TRY(heads(true, p->h_out[key], nout, H, ldin, P, rc, rag, s));
+                continue;
+            }
             // (ragged: the gradient rows of the observed entries are read through the row list; the dense column
             // sums below are unaffected, the gradient is zero where the entry is missing)
             SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s, rag ? RAG_CNT | RAG_AIDX : 0));
@@ -859,8 +895,12 @@ static int generate(shivae_plan* p, const float* u, const float* eps, float temp
         SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s));
         SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s));
         for (auto& kv : p->f_out) {
-            const int key = kv.first, nout = key < 0 ? -key : key;
-            SV_TRY(gemmg(NT, rc, nout, H, key < 0 ? ldA1 : ldHH, H, P, 0, EPI_BIAS, kv.second, s));
+            const int key = kv.first, nout = key < 0 ? -key : key, ldin = key < 0 ? ldA1 : ldHH;
+            if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
+                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rc, false, s));
+                continue;
+            }
+            SV_TRY(gemmg(NT, rc, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s));
         }
         SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
                                     hipMemcpyDeviceToDevice, s));
@@ -952,6 +992,8 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
     {
         const char* f = getenv("SHIVAE_COMPACT");
         p->compact = f ? atoi(f) != 0 : 1;
+        const char* hm = getenv("SHIVAE_HEADS");
+        p->stream_heads = !(hm && strcmp(hm, "gemm") == 0);
     }
     build_workspace(p);
     *out = p;
@@ -1003,7 +1045,7 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
     SV_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0,
                "plan_bind: parameter/gradient buffers must be 16-B aligned");
     release_bound(p);
-    p->f_out.clear(); p->b_out_w.clear(); p->b_out_d.clear(); p->c_out.clear();
+    p->f_out.clear(); p->b_out_w.clear(); p->b_out_d.clear(); p->c_out.clear(); p->h_out.clear();
     p->ws = static_cast<char*>(ws);
     p->params = params;
     p->grads = grads;

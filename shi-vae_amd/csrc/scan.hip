@@ -34,21 +34,43 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int qidx(int tile, int q, int j) { return ((tile * 4 + q) * 16 + j) * 4; }
 
-// acc[a] += Wp(tile nt[a]) * in, summed over KB k-blocks of 16
+// acc[a] += Wp(tile nt[a]) * in, summed over KB k-blocks of 16.
+// Software-pipelined: the weights stream from L2 every timestep (3.1 MB at H=256: they do not fit one CU's LDS), so
+// each k-block's float4 would otherwise be requested right in front of the four MFMAs that consume it and the L2
+// round trip (~700 cycles against 128 cycles of MFMA) would sit on the serial chain.  DEPTH k-blocks of weights
+// are kept in flight (16 registers whatever NA is); the tail re-requests the last block instead of branching.
 template <int NA>
 __device__ __forceinline__ void mma_acc(f32x4 (&acc)[NA], const float* __restrict__ W, int KB, const int (&nt)[NA],
                                         const float* in, int lane) {
+    constexpr int DEPTH = NA >= 4 ? 1 : (NA >= 2 ? 2 : 4);
     const int j = lane & 15, q = lane >> 4;
-
-    for (int kb = 0; kb < KB; ++kb) {
-        const float4 b = *reinterpret_cast<const float4*>(in + qidx(kb, q, j));
+    const float4* Wl = reinterpret_cast<const float4*>(W) + lane;
+    float4 wq[DEPTH][NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const float4 w = *reinterpret_cast<const float4*>(W + ((size_t)(nt[a] * KB + kb) * 64 + lane) * 4);
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, acc[a], 0, 0, 0);
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, acc[a], 0, 0, 0);
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, acc[a], 0, 0, 0);
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, acc[a], 0, 0, 0);
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) wq[d][a] = Wl[(size_t)(nt[a] * KB + min(d, KB - 1)) * 64];
+    for (int kb0 = 0; kb0 < KB; kb0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kb = kb0 + d;
+            if (kb < KB) {  // (wave-uniform)
+                const float4 b = *reinterpret_cast<const float4*>(in + qidx(kb, q, j));
+                float4 w[NA];
+                const int kn = min(kb + DEPTH, KB - 1);
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    w[a] = wq[d][a];
+                    wq[d][a] = Wl[(size_t)(nt[a] * KB + kn) * 64];
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].x, b.x, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].y, b.y, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].z, b.z, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].w, b.w, acc[a], 0, 0, 0);
+                }
+            }
         }
     }
 }
@@ -85,6 +107,14 @@ __device__ __forceinline__ f32x4 ld4(const float* p) {
     return f32x4{v.x, v.y, v.z, v.w};
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+// Records go to HBM and are not read again by this kernel; the packed weights are re-read every timestep.  Streaming
+// (non-temporal) stores / loads for the records keep them from pushing the 3 MB of weights out of the XCD's 4 MiB L2.
+__device__ __forceinline__ void stg4(float* p, f32x4 v) {
+    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f32x4*)p);
+}
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) f32x4*)p);
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 __device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0.f ? v[0] : 0.f, a[1] > 0.f ? v[1] : 0.f, a[2] > 0.f ? v[2] : 0.f, a[3] > 0.f ? v[3] : 0.f}; }
 
@@ -142,8 +172,8 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
             const bool ld = live && ownok[s];
-            xs_pf[s] = ld ? ld4(a.xs_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
-            ex_pf[s] = ld ? ld4(a.ex_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
+            xs_pf[s] = ld ? ldg4(a.xs_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
+            ex_pf[s] = ld ? ldg4(a.ex_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
         }
         float eps_pf[4] = {0.f, 0.f, 0.f, 0.f}, u_pf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
         if (wid < ZT && live) {
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 if (ownok[s]) {
                     const f32x4 v = relu4(acc[s] + xs_pf[s]);
                     st4(bufA + qidx(own[s], q, j), v);
-                    if (live) st4(a.as_ + row * Hp + own[s] * 16 + 4 * q, v);
+                    if (live) stg4(a.as_ + row * Hp + own[s] * 16 + 4 * q, v);
                 }
             mma_acc<MAXS>(e1acc, Wb + a.w.e0h, HT, own, h, lane);
         }
@@ -214,9 +244,9 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 }
                 st4(sbuf + qidx(0, q, j), sv);
                 if (live) {
-                    st4(a.logits + row * Kp + 4 * q, lv4);
-                    st4(a.probs + row * Kp + 4 * q, pv);
-                    st4(a.emb + row * Ep + Hp + 4 * q, sv);
+                    stg4(a.logits + row * Kp + 4 * q, lv4);
+                    stg4(a.probs + row * Kp + 4 * q, pv);
+                    stg4(a.emb + row * Ep + Hp + 4 * q, sv);
                 }
             }
         } else {
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 if (ownok[s]) {
                     const f32x4 v = relu4(e1acc[s] + ex_pf[s]);
                     st4(bufB + qidx(own[s], q, j), v);
-                    if (live) st4(a.e1 + row * Hp + own[s] * 16 + 4 * q, v);
+                    if (live) stg4(a.e1 + row * Hp + own[s] * 16 + 4 * q, v);
                 }
         }
         __syncthreads();
@@ -296,7 +326,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                     const int n = own[s] * 16 + 4 * q;
                     const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_e2 + n));
                     st4(bufA + qidx(own[s], q, j), v);
-                    if (live) st4(a.e2 + row * Hp + n, v);
+                    if (live) stg4(a.e2 + row * Hp + n, v);
                 }
         }
         __syncthreads();
@@ -319,9 +349,9 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             }
             st4(zbuf + qidx(zt, q, j), z);
             if (live) {
-                st4(a.mu + row * Zp + n, mu);
-                st4(a.sd + row * Zp + n, sd);
-                st4(a.z + row * Zp + n, z);
+                stg4(a.mu + row * Zp + n, mu);
+                stg4(a.sd + row * Zp + n, sd);
+                stg4(a.z + row * Zp + n, z);
             }
         }
         __syncthreads();
@@ -337,7 +367,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                     const int n = own[s] * 16 + 4 * q;
                     const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_pz + n));
                     st4(bufB + qidx(own[s], q, j), v);
-                    if (live) st4(a.emb + row * Ep + n, v);
+                    if (live) stg4(a.emb + row * Ep + n, v);
                 }
         }
         __syncthreads();
@@ -365,10 +395,10 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 st4(hn + qidx(ht, q, j), hv);
                 if (live) {
                     float* gp = a.gates + row * 4 * Hp + n;
-                    st4(gp, gi); st4(gp + Hp, gf); st4(gp + 2 * Hp, gg); st4(gp + 3 * Hp, go);
-                    st4(a.cnew + row * Hp + n, cn);
-                    if (t + 1 < a.T) st4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
-                    else if (a.h_last) st4(a.h_last + (size_t)bj * Hp + n, hv);
+                    stg4(gp, gi); stg4(gp + Hp, gf); stg4(gp + 2 * Hp, gg); stg4(gp + 3 * Hp, go);
+                    stg4(a.cnew + row * Hp + n, cn);
+                    if (t + 1 < a.T) stg4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
+                    else if (a.h_last) stg4(a.h_last + (size_t)bj * Hp + n, hv);
                 }
             }
         }
@@ -480,9 +510,9 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
             }
             st4(zbuf + qidx(zt, q, j), z);
             if (live) {
-                st4(a.mu + row * Zp + n, mu);
-                st4(a.sd + row * Zp + n, sd);
-                st4(a.z + row * Zp + n, z);
+                stg4(a.mu + row * Zp + n, mu);
+                stg4(a.sd + row * Zp + n, sd);
+                stg4(a.z + row * Zp + n, z);
             }
         }
         __syncthreads();
@@ -498,7 +528,7 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
                     const int n = own[s] * 16 + 4 * q;
                     const f32x4 v = relu4(acc[s] + ld4(Wb + a.w.b_pz + n));
                     st4(bufB + qidx(own[s], q, j), v);
-                    if (live) st4(a.emb + row * Ep + n, v);
+                    if (live) stg4(a.emb + row * Ep + n, v);
                 }
         }
         __syncthreads();
@@ -523,8 +553,8 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
                 creg[s] = cn;
                 st4(hn + qidx(ht, q, j), hv);
                 if (live) {
-                    if (t == 0) st4(a.emb + row * Ep + Hp + Kp + n, zero4);  // h_{-1} = 0 record of the first step
-                    if (t + 1 < a.T) st4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
+                    if (t == 0) stg4(a.emb + row * Ep + Hp + Kp + n, zero4);  // h_{-1} = 0 record of the first step
+                    if (t + 1 < a.T) stg4(a.emb + (row + B) * Ep + Hp + Kp + n, hv);  // h_prev of step t+1
                 }
             }
         }
@@ -578,8 +608,8 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 if (live) {
                     const float* gp = a.gates + row * 4 * Hp + n;
                     gi = ld4(gp); gf = ld4(gp + Hp); gg = ld4(gp + 2 * Hp); go = ld4(gp + 3 * Hp);
-                    cn = ld4(a.cnew + row * Hp + n);
-                    if (t > 0) cp = ld4(a.cnew + (row - B) * Hp + n);
+                    cn = ldg4(a.cnew + row * Hp + n);
+                    if (t > 0) cp = ldg4(a.cnew + (row - B) * Hp + n);
                 }
                 f32x4 di, df, dg, dO, dc = dcreg[s];
 #pragma unroll
@@ -599,7 +629,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 st4(dgb + qidx(3 * HT + ht, q, j), dO);
                 if (live) {
                     float* gp = a.d_gates + row * 4 * Hp + n;
-                    st4(gp, di); st4(gp + Hp, df); st4(gp + 2 * Hp, dg); st4(gp + 3 * Hp, dO);
+                    stg4(gp, di); stg4(gp + Hp, df); stg4(gp + 2 * Hp, dg); stg4(gp + 3 * Hp, dO);
                 }
             }
         }
@@ -610,10 +640,10 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
                 const int n = nt * 16 + 4 * q;
                 f32x4 pz = zero4;
-                if (live) { v += ld4(a.d_emb + row * Ep + n); pz = ld4(a.emb + row * Ep + n); }
+                if (live) { v += ldg4(a.d_emb + row * Ep + n); pz = ldg4(a.emb + row * Ep + n); }
                 v = gate4(v, pz);
                 st4(bufB + qidx(nt, q, j), v);
-                if (live) st4(a.d_phiz_pre + row * Hp + n, v);
+                if (live) stg4(a.d_phiz_pre + row * Hp + n, v);
             });
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) {
@@ -635,8 +665,8 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             const int n = zt * 16 + 4 * q;
             f32x4 dmu = acc[0], dsd = zero4;
             if (live) {
-                dmu += ld4(a.dmu_ext + row * Zp + n);
-                const f32x4 de = ld4(a.dsd_ext + row * Zp + n), sd = ld4(a.sd + row * Zp + n);
+                dmu += ldg4(a.dmu_ext + row * Zp + n);
+                const f32x4 de = ldg4(a.dsd_ext + row * Zp + n), sd = ldg4(a.sd + row * Zp + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = (n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
@@ -646,8 +676,8 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             st4(dmub + qidx(zt, q, j), dmu);
             st4(dsdb + qidx(zt, q, j), dsd);
             if (live) {
-                st4(a.d_mu + row * Zp + n, dmu);
-                st4(a.d_sd_pre + row * Zp + n, dsd);
+                stg4(a.d_mu + row * Zp + n, dmu);
+                stg4(a.d_sd_pre + row * Zp + n, dsd);
             }
         }
         __syncthreads();
@@ -656,9 +686,9 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             const Src src[2] = {{Wb + a.w.t_mu, dmub, ZT}, {Wb + a.w.t_sd, dsdb, ZT}};
             layer<2>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
                 const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ld4(a.e2 + row * Hp + n) : zero4);
+                v = gate4(v, live ? ldg4(a.e2 + row * Hp + n) : zero4);
                 st4(bufA + qidx(nt, q, j), v);
-                if (live) st4(a.d_e2_pre + row * Hp + n, v);
+                if (live) stg4(a.d_e2_pre + row * Hp + n, v);
             });
         }
         __syncthreads();
@@ -667,9 +697,9 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             const Src src[1] = {{Wb + a.w.t_e2, bufA, HT}};
             layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
                 const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ld4(a.e1 + row * Hp + n) : zero4);
+                v = gate4(v, live ? ldg4(a.e1 + row * Hp + n) : zero4);
                 st4(bufB + qidx(nt, q, j), v);
-                if (live) st4(a.d_e1_pre + row * Hp + n, v);
+                if (live) stg4(a.d_e1_pre + row * Hp + n, v);
             });
         }
         __syncthreads();
@@ -677,7 +707,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
         {
             const Src src[1] = {{Wb + a.w.t_e0s, bufB, HT}};
             layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                if (live) v += ld4(a.d_emb + row * Ep + Hp + nt * 16 + 4 * q);
+                if (live) v += ldg4(a.d_emb + row * Ep + Hp + nt * 16 + 4 * q);
                 st4(dsb + qidx(nt, q, j), v);
             });
 #pragma unroll
@@ -718,9 +748,9 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             const Src src[1] = {{Wb + a.w.t_lg, dlgb, KT}};
             layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
                 const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ld4(a.as_ + row * Hp + n) : zero4);
+                v = gate4(v, live ? ldg4(a.as_ + row * Hp + n) : zero4);
                 st4(bufA + qidx(nt, q, j), v);
-                if (live) st4(a.d_as_pre + row * Hp + n, v);
+                if (live) stg4(a.d_as_pre + row * Hp + n, v);
             });
         }
         __syncthreads();
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 const int nt[1] = {ht};
                 f32x4 acc[1] = {dhacc[s]};
                 mma_acc<1>(acc, Wb + a.w.t_xsh, HT, nt, bufA, lane);
-                if (live) acc[0] += ld4(a.d_emb + row * Ep + Hp + Kp + ht * 16 + 4 * q);
+                if (live) acc[0] += ldg4(a.d_emb + row * Ep + Hp + Kp + ht * 16 + 4 * q);
                 st4(dhb + qidx(ht, q, j), acc[0]);
             }
         }
@@ -780,7 +810,7 @@ int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int 
 }
 
 // ---------------------------------------------------------------------------------- launch
-static int scan_geometry(const ScanArgs& a, int& nw, int& maxs) {
+static int scan_geometry(const ScanArgs& a, int& nw, int& maxs, bool bwd = false) {
     // waves per workgroup: one per 16 hidden units up to 16 waves (4 per SIMD hide the L2 latency of
     // the streamed weights); each wave keeps ceil(HT/nw) cell-state tiles in registers
     const int HT = a.Hp / 16;
@@ -788,6 +818,11 @@ static int scan_geometry(const ScanArgs& a, int& nw, int& maxs) {
     while (nw * 2 <= HT && nw < 16) nw *= 2;
     static const int force = [] { const char* f = getenv("SHIVAE_SCAN_WAVES"); return f ? atoi(f) : 0; }();
     if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) nw = std::min(nw, force);
+    // The forward chain runs best on 8 waves (256 registers each: the pipelined weight fetch and the gate
+    // accumulators stay in registers; with 16 waves at 128 registers it spilled ~100 of them): 80.3 ms against 90.0 ms
+    // for B=4096, T=1000 at H=256.  The reverse chain has more independent MFMA work per phase and wants the 16 waves
+    // (101.9 ms against 131.8 ms).
+    else if (!bwd) nw = std::min(nw, 8);
     const int need = ceil_div(HT, nw);
     maxs = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
     SV_REQUIRE(need <= 8, "scan: h_dim %d too large for the register-resident cell", a.H);
@@ -813,7 +848,7 @@ static int launch_scan_t(const ScanArgs& a, bool bwd, int nw, hipStream_t stream
 int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream) {
     if (a.T <= 0 || a.B <= 0) return SHIVAE_OK;
     int nw, maxs;
-    SV_TRY(scan_geometry(a, nw, maxs));
+    SV_TRY(scan_geometry(a, nw, maxs, bwd));
     if (nw == 8) {
         switch (maxs) {
             case 1: return launch_scan_t<1, 512>(a, bwd, nw, stream);
