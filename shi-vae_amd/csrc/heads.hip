@@ -87,6 +87,67 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
     }
 }
 
+// Sum over the 16 lanes of a DPP row (no LDS round trip): quad xor 1, quad xor 2, half-row mirror, row mirror.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+// Forward, fast form (H a multiple of 64): 16 lanes share a row (lane c owns columns 4c + 64 i), so a wave has four
+// rows in flight per step and eight per unrolled iteration; the dot products are reduced inside the DPP row.
+template <int NOUT, int NI>  // NI = H / 64
+__global__ __launch_bounds__(256) void head_fwd16_kernel(HeadParams p) {
+    const HeadGroup g = p.groups[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = lane & 15, sub = lane >> 4;
+    const int n = p.use_cnt ? min(*g.cnt, p.rows) : p.rows;
+    const int r0 = wave * p.rows_per_wave, r1 = min(n, r0 + p.rows_per_wave);
+    if (r0 >= r1) return;
+    float4 w[NOUT][NI];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w[j][i] = hload4(g.W + (size_t)j * p.H + 4 * c + 64 * i);
+    float b[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) b[j] = g.b[j];
+    constexpr int U = 2;  // row quads per iteration
+    for (int base = r0; base < r1; base += 4 * U) {
+        float4 h[U][NI];
+        int row[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + 4 * u + sub;
+            ok[u] = i < r1;
+            const int ii = ok[u] ? i : r1 - 1;
+            row[u] = p.use_idx ? g.idx[ii] : ii;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) h[u][k] = hload4(g.hin + (size_t)ii * p.ldin + 4 * c + 64 * k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc[NOUT];
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < NI; ++k)
+                    a += h[u][k].x * w[j][k].x + h[u][k].y * w[j][k].y + h[u][k].z * w[j][k].z + h[u][k].w * w[j][k].w;
+                acc[j] = row16_sum(a);
+            }
+            if (c == 0 && ok[u]) {
+                float* o = g.P + (size_t)row[u] * p.ldp;
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) o[j] = acc[j] + b[j];
+            }
+        }
+    }
+}
+
 template <int NOUT, int CB>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     const HeadGroup g = p.groups[blockIdx.y];
@@ -110,30 +171,47 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     float gb[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) gb[j] = 0.f;
-    for (int i = r0; i < r1; ++i) {
-        const int row = p.use_idx ? g.idx[i] : i;
-        const float* dp = g.P + (size_t)row * p.ldp;  // (wave-uniform address: one broadcast load per column)
-        float d[NOUT];
+    constexpr int U = 4;  // rows in flight per wave (memory-level parallelism: 4 KB of loads + 4 KB of stores)
+    for (int base = r0; base < r1; base += U) {
+        float d[U][NOUT];
+        float4 h[U][CB];
+        bool ok[U];
+        size_t off[U];
 #pragma unroll
-        for (int j = 0; j < NOUT; ++j) {
-            d[j] = *(hgbl_f32_ptr)(dp + j);
-            gb[j] += d[j];
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u;
+            ok[u] = i < r1;
+            const int ii = ok[u] ? i : r1 - 1;
+            const int row = p.use_idx ? g.idx[ii] : ii;
+            const float* dp = g.P + (size_t)row * p.ldp;  // (wave-uniform address: one broadcast load per column)
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) d[u][j] = *(hgbl_f32_ptr)(dp + j);
+            off[u] = (size_t)ii * p.ldin + lane * 4;
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                h[u][c] = live[c] ? hload4(g.hin + off[u] + c * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            if (!live[c]) continue;
-            const size_t off = (size_t)i * p.ldin + c * 256 + lane * 4;
-            const float4 h = hload4(g.hin + off);
-            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;  // (wave-uniform)
 #pragma unroll
-            for (int j = 0; j < NOUT; ++j) {
-                dh.x += d[j] * w[j][c].x; dh.y += d[j] * w[j][c].y; dh.z += d[j] * w[j][c].z; dh.w += d[j] * w[j][c].w;
-                gw[j][c].x += d[j] * h.x; gw[j][c].y += d[j] * h.y; gw[j][c].z += d[j] * h.z; gw[j][c].w += d[j] * h.w;
+            for (int j = 0; j < NOUT; ++j) gb[j] += d[u][j];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                if (!live[c]) continue;
+                const float4 hv = h[u][c];
+                float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    const float dj = d[u][j];
+                    dh.x += dj * w[j][c].x; dh.y += dj * w[j][c].y; dh.z += dj * w[j][c].z; dh.w += dj * w[j][c].w;
+                    gw[j][c].x += dj * hv.x; gw[j][c].y += dj * hv.y; gw[j][c].z += dj * hv.z; gw[j][c].w += dj * hv.w;
+                }
+                dh.x = hv.x > 0.f ? dh.x : 0.f; dh.y = hv.y > 0.f ? dh.y : 0.f;
+                dh.z = hv.z > 0.f ? dh.z : 0.f; dh.w = hv.w > 0.f ? dh.w : 0.f;
+                hstore4(g.dhin + off[u] + c * 256, dh);
+                cs[c].x += dh.x; cs[c].y += dh.y; cs[c].z += dh.z; cs[c].w += dh.w;
             }
-            dh.x = h.x > 0.f ? dh.x : 0.f; dh.y = h.y > 0.f ? dh.y : 0.f;
-            dh.z = h.z > 0.f ? dh.z : 0.f; dh.w = h.w > 0.f ? dh.w : 0.f;
-            hstore4(g.dhin + off, dh);
-            cs[c].x += dh.x; cs[c].y += dh.y; cs[c].z += dh.z; cs[c].w += dh.w;
         }
     }
     // one atomic per (wave, column): ~100 waves per attribute
@@ -162,8 +240,13 @@ bool head_kernels_fit(int H, int nout, int ldin, int ldp) {
 
 template <int NOUT, int CB>
 static void launch_one(bool bwd, const HeadParams& p, dim3 grid, hipStream_t s) {
-    if (bwd) hipLaunchKernelGGL((head_bwd_kernel<NOUT, CB>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((head_fwd_kernel<NOUT, CB>), grid, dim3(256), 0, s, p);
+    if (bwd) { hipLaunchKernelGGL((head_bwd_kernel<NOUT, CB>), grid, dim3(256), 0, s, p); return; }
+    if constexpr (NOUT <= 4) {  // (weights of the fast forward form: NOUT * H/16 registers)
+        if (p.H == 256) { hipLaunchKernelGGL((head_fwd16_kernel<NOUT, 4>), grid, dim3(256), 0, s, p); return; }
+        if (p.H == 128) { hipLaunchKernelGGL((head_fwd16_kernel<NOUT, 2>), grid, dim3(256), 0, s, p); return; }
+        if (p.H == 64) { hipLaunchKernelGGL((head_fwd16_kernel<NOUT, 1>), grid, dim3(256), 0, s, p); return; }
+    }
+    hipLaunchKernelGGL((head_fwd_kernel<NOUT, CB>), grid, dim3(256), 0, s, p);
 }
 template <int CB>
 static void launch_nout(int nout, bool bwd, const HeadParams& p, dim3 grid, hipStream_t s) {
