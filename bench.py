@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-step", action="store_true",
                     help="skip the warm-up step under the library's HIP events (runs under rocprofv3 --pmc)")
+    ap.add_argument("--no-split-mode", action="store_true",
+                    help="skip the extra timing of the split-bf16 GEMM mode (reported next to the fp32-MFMA headline)")
     ap.add_argument("--budget", type=float, default=float(os.environ.get("SHIVAE_BENCH_BUDGET_S", "480")),
                     help="wall-clock seconds for the whole process; counts are clamped to fit")
     a = ap.parse_args()
@@ -249,7 +251,14 @@ def main():
         say("profiled warm-up step: %.3f s" % prof_dt)
 
     # ---- how many more steps fit the budget (same decision on every rank)
+    # (the split-bf16 mode is timed afterwards on 1 warm-up + 3 steps of ~0.8 of an fp32 step each, when that fits
+    # next to at least 4 fp32 steps)
     left = a.budget - (time.perf_counter() - T_PROC0) - 5.0
+    want_split = not a.no_split_mode and not a.no_profile_step
+    split_cost = 4 * 0.8 * prof_dt if want_split else 0.0
+    if want_split and (left - split_cost) / (prof_dt * 1.02) < min(a.steps, 4):
+        want_split, split_cost = False, 0.0
+    left -= split_cost
     afford = int(left / (prof_dt * 1.02))
     if dist is not None:
         tt = torch.tensor([afford], device="cuda", dtype=torch.int64)
@@ -272,7 +281,29 @@ def main():
         marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
-    per = torch.tensor([marks[i + 1] - marks[i] for i in range(steps)] + [dt], device="cuda", dtype=torch.float64)
+    # ---- the same step with the decoder GEMMs in split-bf16 arithmetic (exact 3-way bf16 split of every fp32 operand,
+    #      six bf16 MFMA products per fp32 product, fp32 accumulation; shivae_set_gemm_split).  Reported beside the
+    #      headline, never instead of it.
+    split_times = []
+    if dist is not None:
+        ws = torch.tensor([1 if want_split else 0], device="cuda")
+        dist.all_reduce(ws, op=dist.ReduceOp.MIN)
+        want_split = bool(int(ws))
+    if want_split:
+        N.lib().shivae_set_gemm_split(1)
+        step()
+        fence()
+        m0 = time.perf_counter()
+        for _ in range(3):
+            loss_s = step()
+            torch.cuda.synchronize()
+            m1 = time.perf_counter()
+            split_times.append(m1 - m0)
+            m0 = m1
+        fence()
+        N.lib().shivae_set_gemm_split(0)
+        say("split-bf16 mode: %s s" % ", ".join("%.3f" % t for t in split_times))
+    per = torch.tensor([marks[i + 1] - marks[i] for i in range(steps)] + [dt] + split_times, device="cuda", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(per, op=dist.ReduceOp.MAX)
         lv = loss["n_elbo"].detach().clone()
@@ -284,6 +315,7 @@ def main():
             dist.destroy_process_group()
         return
     per = per.tolist()
+    split_times = [per.pop() for _ in split_times][::-1]
     dt = per.pop()
     med = sorted(per)[len(per) // 2] if len(per) % 2 else 0.5 * (sorted(per)[len(per) // 2 - 1] + sorted(per)[len(per) // 2])
     ms_step = med * 1e3
@@ -329,6 +361,14 @@ def main():
                       "missing_frac": round(float(mask.float().mean()), 4)},
            "wall_s": time.perf_counter() - T_PROC0, "budget_s": a.budget,
            "n_elbo": float(lv), "roofline": roof, "roofline_other_kernels": others}
+    if split_times:
+        sm = sorted(split_times)[len(split_times) // 2]
+        out["split_bf16_mode"] = {
+            "value": B * T / sm, "unit": "sequence-timesteps/s", "ms_per_step": sm * 1e3, "steps": len(split_times),
+            "warmup": 1, "n_elbo": float(loss_s["n_elbo"].detach()) if dist is None else None,
+            "arithmetic": "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, fp32 "
+                          "accumulation (opt-in: shivae_set_gemm_split / SHIVAE_GEMM_SPLIT=1); same parity tests and "
+                          "tolerances as the fp32-MFMA mode"}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)

@@ -232,6 +232,13 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
                 int ldc, const float* bias, const float* aux, int ldaux, int epi, int splitk,
                 shivae_stream stream);
 
+/* Arithmetic of the 128x128-tile GEMMs (the decoder: 99 % of the step's flops).  0 (default): fp32-input MFMA
+ * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  1: every fp32 operand is split EXACTLY into three bf16 terms and
+ * a product is accumulated in fp32 from the six bf16 MFMA products that matter (v_mfma_f32_32x32x16_bf16; the
+ * dropped cross terms are <= 2^-23 of the product): same inputs, same outputs, fp32-level error, 2-3x the rate.
+ * Also selectable with SHIVAE_GEMM_SPLIT=1.  No counterpart in the reference. */
+int shivae_set_gemm_split(int on);
+
 /* ---- optimiser ------------------------------------------------------------------------------ */
 int shivae_zero(float* buf_dev, int64_t n, shivae_stream stream);
 /* sum of squares of a flat buffer -> *out_dev (overwritten); scratch_dev: >= 1024 floats */

@@ -31,7 +31,7 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
            "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
-           "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
+           "shivae_set_gemm_split", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
            "shivae_allreduce_grads",
            "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
@@ -82,6 +82,7 @@ def lib():
     L.shivae_decoder_nll.argtypes = [vp, vp, vp, cf, ci, vp]
     L.shivae_scan_bwd.argtypes = [vp, vp, vp, vp, cf, vp, vp, vp, vp, vp]
     L.shivae_loss_reduce.argtypes = [vp, cf, cf, vp, vp]
+    L.shivae_set_gemm_split.argtypes = [ci]
     L.shivae_sqnorm_noalloc.argtypes = [vp, i64, vp, vp]
     L.shivae_comm_unique_id.argtypes = [vp]
     L.shivae_comm_init.argtypes = [C.POINTER(vp), ci, ci, vp]
@@ -180,7 +181,7 @@ class Plan:
         return int(lib().shivae_output_width(self.h, which))
 
 
-_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128", "128x256"]
+_TILES = ["256x32", "32x256", "256x64", "64x256", "128x128", "128x128 split-bf16"]
 _LAYOUTS = ["NT", "NN", "TN"]
 
 

@@ -34,7 +34,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
-// ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x256)
+// ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x128 split-bf16)
 enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_COUNT = 24 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);
@@ -92,6 +92,7 @@ struct GemmDesc {
 };
 
 extern unsigned long long* g_gemm_stamps;  // diagnostics: see shivae_debug_gemm_stamps
+extern int g_gemm_split;                    // see shivae_set_gemm_split
 
 // groups_dev: device array of ngroups GemmGroup, or nullptr with ngroups==1 and g0 used.
 int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,

@@ -59,7 +59,32 @@ __device__ __forceinline__ void gatomic_add(float* p, float v) {
     __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool KC, int ROWS, int NT, bool VEC>
+// ---- fp32 products on the bf16 matrix cores ("split" mode, SHIVAE_GEMM_SPLIT / shivae_set_gemm_split) ----------
+// An fp32 value is the exact sum of three bf16 values when each is taken by TRUNCATION: hi = upper 16 bits of x,
+// mid = upper 16 bits of (x - hi), lo = upper 16 bits of (x - hi - mid) -- 3 x 8 significand bits = the 24 of fp32,
+// every subtraction exact.  a*b is then accumulated in fp32 as the six bf16 products whose magnitude is >= 2^-16 of
+// the leading one (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi); the dropped ones (mid*lo, lo*mid, lo*lo) are
+// <= 2^-23 |a b|, the size of ONE fp32 rounding of the product.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
+// the fp32-input MFMA, so six of them per product still give 2.67x its throughput.
+// LDS images of a split tile (bf16, built when the fp32 registers are parked in LDS):
+//   K-contiguous operand  : [rows][104] halves = hi[32] | mid[32] | lo[32] | pad[8]; a lane's fragment of one plane
+//                           (8 consecutive k) is one ds_read_b128; 208-B rows are conflict-free for them
+//   row-contiguous operand: [plane][16 k-pairs][rows] dwords, a dword = the bf16 pair (k, k+1) of one row; a
+//                           fragment is 4 ds_read_b32 (consecutive rows -> consecutive banks)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SPLIT_RS = 104;  // halves per row of the K-contiguous split image
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // {bf16 trunc(a), bf16 trunc(b)} as one dword
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302);
+}
+__device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) {
+    hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r = x - hi;
+    mid = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    lo = r - mid;  // (<= 8 significant bits left: its upper half is exact)
+}
+
+template <bool KC, int ROWS, int NT, bool VEC, bool SPLIT = false>
 struct TileLoader {
     // KC : global X[row*ld + k], tile rows = ROWS along the M/N extent, 32 along K
     // !KC: global X[k*ld + row]
@@ -71,8 +96,18 @@ struct TileLoader {
     // the k-row of the NEXT load() and is refreshed one K-tile ahead, so the index fetch never sits between a
     // load() and its data.
     static constexpr int NV = ROWS * 8 / NT;  // float4 per thread
+    static constexpr int TPR = ROWS / 4;      // !KC: threads per k-row
     float4 v[NV > 0 ? NV : 1];
     int src[NV > 0 ? NV : 1];
+
+    // piece i of thread tid -> (tile row, tile k).  Split mode gives a thread of a row-contiguous operand NV
+    // CONSECUTIVE k of the same four rows, so that it can pack (k, k+1) bf16 pairs.
+    __device__ __forceinline__ static int prow(int i, int tid) {
+        return KC ? (tid + i * NT) >> 3 : ((SPLIT ? tid : tid + i * NT) % TPR) * 4;
+    }
+    __device__ __forceinline__ static int pk(int i, int tid) {
+        return KC ? ((tid + i * NT) & 7) * 4 : (SPLIT ? NV * (tid / TPR) + i : (tid + i * NT) / TPR);
+    }
 
     // (the list is read unconditionally -- without a list, a dummy word of the operand itself -- and selected
     // afterwards: a branch around the load would put a full vmcnt(0) wait into the K loop)
@@ -85,20 +120,15 @@ struct TileLoader {
     __device__ __forceinline__ void init(const int* __restrict__ idx, const float* __restrict__ X, int row0, int nrows,
                                          int k0, int kend, int tid) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * NT;
-            src[i] = KC ? pick(idx, X, row0 + (f >> 3), nrows) : pick(idx, X, k0 + f / (ROWS / 4), kend);
-        }
+        for (int i = 0; i < NV; ++i)
+            src[i] = KC ? pick(idx, X, row0 + prow(i, tid), nrows) : pick(idx, X, k0 + pk(i, tid), kend);
     }
 
     __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int row0, int nrows, int k0,
                                          int kend, int tid, const int* __restrict__ idx) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * NT;
-            int r, k;
-            if (KC) { r = f >> 3; k = (f & 7) * 4; }
-            else    { k = f / (ROWS / 4); r = (f % (ROWS / 4)) * 4; }
+            const int r = prow(i, tid), k = pk(i, tid);
             const int gr = row0 + r, gk = k0 + k;
             const size_t off = KC ? (size_t)src[i] * ld + gk : (size_t)src[i] * ld + gr;
             const gbl_f32_ptr Xg = (gbl_f32_ptr)X;
@@ -119,21 +149,69 @@ struct TileLoader {
         }
         if (!KC) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) src[i] = pick(idx, X, k0 + 32 + (tid + i * NT) / (ROWS / 4), kend);
+            for (int i = 0; i < NV; ++i) src[i] = pick(idx, X, k0 + 32 + pk(i, tid), kend);
         }
     }
 
     __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * NT;
-            int off;
-            if (KC) off = (f >> 3) * 36 + (f & 7) * 4;
-            else    off = (f / (ROWS / 4)) * ROWS + (f % (ROWS / 4)) * 4;
+            const int r = prow(i, tid), k = pk(i, tid);
+            const int off = KC ? r * 36 + k : k * ROWS + r;
             *reinterpret_cast<float4*>(lds + off) = v[i];
         }
     }
+
+    // split mode: park the tile as three bf16 planes (layouts above)
+    __device__ __forceinline__ void store_split(float* lds, int tid) const {
+        unsigned* l32 = reinterpret_cast<unsigned*>(lds);
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = prow(i, tid), k = pk(i, tid);
+                float h[4], m[4], l[4];
+                split3(v[i].x, h[0], m[0], l[0]); split3(v[i].y, h[1], m[1], l[1]);
+                split3(v[i].z, h[2], m[2], l[2]); split3(v[i].w, h[3], m[3], l[3]);
+                unsigned* d = l32 + (r * SPLIT_RS + k) / 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+                *reinterpret_cast<uint2*>(d + 16) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+                *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+            }
+        } else {
+            static_assert(KC || NV % 2 == 0, "row-contiguous split tiles pack k pairs");
+#pragma unroll
+            for (int i = 0; i + 1 < NV; i += 2) {
+                const int r = prow(i, tid), k = pk(i, tid);  // k even; piece i+1 is k+1 of the same rows
+                const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, o[4] = {v[i + 1].x, v[i + 1].y, v[i + 1].z, v[i + 1].w};
+                unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float h0, m0, l0, h1, m1, l1;
+                    split3(e[c], h0, m0, l0);
+                    split3(o[c], h1, m1, l1);
+                    ph[c] = pack_hi16(h0, h1); pm[c] = pack_hi16(m0, m1); pl[c] = pack_hi16(l0, l1);
+                }
+                unsigned* d = l32 + (k / 2) * ROWS + r;
+                *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                *reinterpret_cast<uint4*>(d + 16 * ROWS) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+                *reinterpret_cast<uint4*>(d + 32 * ROWS) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
+        }
+    }
 };
+
+// fragment of plane p for k-step s (16 k) of a split tile: the 8 bf16 k = 16 s + 8 h .. + 7 of one row
+template <bool KC, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag_split(const float* lds, int row, int p, int s, int h) {
+    const unsigned* l32 = reinterpret_cast<const unsigned*>(lds);
+    uint4 u;
+    if (KC) u = *reinterpret_cast<const uint4*>(l32 + (row * SPLIT_RS + p * 32 + 16 * s + 8 * h) / 2);
+    else {
+        const unsigned* q = l32 + (p * 16 + 8 * s + 4 * h) * ROWS + row;
+        u = make_uint4(q[0], q[ROWS], q[2 * ROWS], q[3 * ROWS]);
+    }
+    return __builtin_bit_cast(bf16x8, u);
+}
 
 // LDS-DMA staging (global_load_lds_dwordx4): a wave-instruction writes 1 KiB of LDS linearly (wave-uniform base +
 // lane * 16 B) from per-lane global addresses, with no VGPR round trip and no ds_write (the VGPR->LDS transfer
@@ -269,13 +347,14 @@ __device__ __forceinline__ GemmGroup load_group(const GemmParams& p, int gi) {
     return g;
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int WPE, bool DB, bool DMA>
+template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int WPE, bool DB, bool DMA, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     static_assert(!DMA || (DB && VEC), "the LDS-DMA path is the two-stage, 16-B aligned one");
+    static_assert(!SPLIT || (!DMA && !DB), "split mode converts in registers: single LDS stage");
     static_assert(WM * WN <= 8, "at most 8 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-    constexpr int LDS_A = A_KC ? BM * (DMA ? 32 : 36) : 32 * BM;
-    constexpr int LDS_B = B_KC ? BN * (DMA ? 32 : 36) : 32 * BN;
+    constexpr int LDS_A = SPLIT ? (A_KC ? BM * SPLIT_RS / 2 : 48 * BM) : (A_KC ? BM * (DMA ? 32 : 36) : 32 * BM);
+    constexpr int LDS_B = SPLIT ? (B_KC ? BN * SPLIT_RS / 2 : 48 * BN) : (B_KC ? BN * (DMA ? 32 : 36) : 32 * BN);
     constexpr int STAGE = LDS_A + LDS_B;
     // (the epilogue stages 32-row bands of the C tile in the same array: keep room for four of them)
     constexpr int LDS_FLOATS = (DB ? 2 : 1) * STAGE > 4 * 32 * (BN + 4) || !DMA ? (DB ? 2 : 1) * STAGE : 4 * 32 * (BN + 4);
@@ -324,8 +403,8 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    TileLoader<A_KC, BM, NT, VEC> la;
-    TileLoader<B_KC, BN, NT, VEC> lb;
+    TileLoader<A_KC, BM, NT, VEC, SPLIT> la;
+    TileLoader<B_KC, BN, NT, VEC, SPLIT> lb;
     if constexpr (!DMA) {
         la.init(aidx, g.A, m0, Mrows, kbeg, kend, tid);
         lb.init(bidx, g.B, n0, p.N, kbeg, kend, tid);
@@ -359,7 +438,48 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                 }
         }
     };
-    if constexpr (DMA) {
+    auto compute_split = [&](const float* sa, const float* sb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[x][pl] = read_frag_split<A_KC, BM>(sa, (wm * TM + x) * 32 + li, pl, s, lh);
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[y][pl] = read_frag_split<B_KC, BN>(sb, (wn * TN + y) * 32 + li, pl, s, lh);
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {  // smallest terms first
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
+                }
+        }
+    };
+    if constexpr (SPLIT) {
+        if (kbeg < kend) {
+            la.load(g.A, p.lda, m0, Mrows, kbeg, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid, bidx);
+        }
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            la.store_split(ldsA, tid);
+            lb.store_split(ldsB, tid);
+            __syncthreads();
+            if (k0 + 32 < kend) {
+                la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
+                lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
+            }
+            compute_split(ldsA, ldsB);
+            __syncthreads();
+        }
+    } else if constexpr (DMA) {
         // two LDS stages filled by LDS-DMA: the next K-tile streams into the other stage while this one is
         // multiplied; __syncthreads() waits for this wave's DMAs (vmcnt) before the barrier.  The source rows of
         // the tile after next are fetched one step ahead (ragged launches: through the row lists).
@@ -598,13 +718,15 @@ unsigned long long* g_gemm_stamps = nullptr;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int g_gemm_split = -1;  // -1: not set (SHIVAE_GEMM_SPLIT decides at the first launch), 0 / 1: shivae_set_gemm_split
+
 template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int MINB = (TM * TN <= 2 ? 4 : (TM * TN <= 4 ? 3 : 2)), bool DB = false,
-          bool DMA = false>
+          bool DMA = false, bool SPLIT = false>
 static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int layout = A_KC ? (B_KC ? GEMM_NT : GEMM_NN) : GEMM_TN;
-    constexpr int tile = (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
-                       : (BM == 64 && BN == 256) ? 3 : (BM == 128 && BN == 128) ? 4 : 5;
+    constexpr int tile = SPLIT ? 5 : (BM == 256 && BN == 32) ? 0 : (BM == 32 && BN == 256) ? 1 : (BM == 256 && BN == 64) ? 2
+                       : (BM == 64 && BN == 256) ? 3 : 4;
     (void)tile;
     GemmParams q = p;
     q.stamps = g_gemm_stamps;
@@ -631,7 +753,7 @@ static int launch_cfg(const GemmParams& p, int ngroups, hipStream_t stream) {
     dim3 grid((unsigned)nblocks);
     prof_shape(p.M, p.N, p.K, ngroups);
     prof_begin(layout * 6 + tile, 2.0 * p.M * p.N * (double)p.K * ngroups, stream);
-    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN, MINB, DB, DMA>), grid, dim3(WM * WN * 64), 0, stream, q);
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, VEC, WM, WN, TM, TN, MINB, DB, DMA, SPLIT>), grid, dim3(WM * WN * 64), 0, stream, q);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
@@ -649,6 +771,13 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     static const int mode = [] { const char* f = getenv("SHIVAE_GEMM_TILE"); return f ? atoi(f) : 0; }();
     if (mode == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false>(p, ngroups, stream);  // 8 waves, 1 stage
     if constexpr (VEC) {
+        if (g_gemm_split < 0) { const char* f = getenv("SHIVAE_GEMM_SPLIT"); g_gemm_split = f ? atoi(f) != 0 : 0; }
+        // split mode: fp32 products as six bf16 MFMAs (see TileLoader); 128 x 128, 8 waves, one LDS stage
+        if (g_gemm_split > 0) {
+            static const int st = [] { const char* f = getenv("SHIVAE_SPLIT_TILE"); return f ? atoi(f) : 0; }();
+            if (st == 1) return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2, 2, false, false, true>(p, ngroups, stream);  // 4 waves of 64x64
+            return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false, false, true>(p, ngroups, stream);
+        }
         // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands
         // need whole K-tiles, and dense rows (no row lists on this path for them).  Measured in the training step
         // (B=256, T=100, straight-line K loops): TN 127 -> 135 TFLOP/s, NN +3 %; NT (both operands K-contiguous)

@@ -1332,6 +1332,11 @@ int shivae_debug_gemm_stamps(unsigned long long* buf_dev) {
     return SHIVAE_OK;
 }
 
+int shivae_set_gemm_split(int on) {
+    shivae::g_gemm_split = on ? 1 : 0;
+    return SHIVAE_OK;
+}
+
 int shivae_zero(float* buf, int64_t n, shivae_stream stream) {
     SV_REQUIRE(buf && n >= 0, "zero: bad argument");
     SV_CHECK_HIP(hipMemsetAsync(buf, 0, (size_t)n * sizeof(float), static_cast<hipStream_t>(stream)));

@@ -19,6 +19,15 @@ from test_gpu_step import _synth, FWD_RTOL, FWD_ATOL, LOSS_RTOL, GRAD_RTOL
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
+
+@pytest.fixture(params=["f32_mfma", "split_bf16"], autouse=True)
+def gemm_mode(request):
+    """Every test of this module runs in both arithmetic modes of the 128x128-tile GEMMs (shivae_set_gemm_split): the
+    fp32-input MFMA and the exact 3-way bf16 split with six bf16 MFMA products -- same tolerances."""
+    N.lib().shivae_set_gemm_split(1 if request.param == "split_bf16" else 0)
+    yield request.param
+    N.lib().shivae_set_gemm_split(0)
+
 MIXES = {
     # name: (types_list, T, B, H, Z, K, miss, chunk_rows, micro)
     "cfg3_mix": (shivae_amd.utils.make_types_list(64, 64, 64, [4] * 64), 3, 24, 256, 64, 16, 0.3, 20, 16),

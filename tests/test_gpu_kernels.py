@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["f32_mfma", "split_bf16"], autouse=True)
+def gemm_mode(request):
+    """Every test of this module runs in both arithmetic modes of the 128x128-tile GEMMs (shivae_set_gemm_split): the
+    fp32-input MFMA and the exact 3-way bf16 split with six bf16 MFMA products -- same tolerances."""
+    N.lib().shivae_set_gemm_split(1 if request.param == "split_bf16" else 0)
+    yield request.param
+    N.lib().shivae_set_gemm_split(0)
+
+
 def _t(a):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
 

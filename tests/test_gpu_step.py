@@ -18,6 +18,15 @@ LOSS_RTOL = 2e-5
 GRAD_RTOL = 5e-4  # relative to the largest |grad| entry of each tensor
 
 
+@pytest.fixture(params=["f32_mfma", "split_bf16"], autouse=True)
+def gemm_mode(request):
+    """Every test of this module runs in both arithmetic modes of the 128x128-tile GEMMs (shivae_set_gemm_split): the
+    fp32-input MFMA and the exact 3-way bf16 split with six bf16 MFMA products -- same tolerances."""
+    N.lib().shivae_set_gemm_split(1 if request.param == "split_bf16" else 0)
+    yield request.param
+    N.lib().shivae_set_gemm_split(0)
+
+
 def _model(cfg, sd):
     m = shivae_amd.ShiVAE(cfg["H"], cfg["Z"], cfg["K"], 1, types_list=cfg["types_list"], learn_std=cfg["learn_std"])
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
