@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshivae_hip.so")
+LIB_PATH = os.environ.get("SHIVAE_LIB_PATH") or os.path.join(_HERE, "libshivae_hip.so")  # (override: experiment builds)
 
 REAL, POS, BIN, CAT = 0, 1, 2, 3
 TYPE_CODE = {"real": REAL, "pos": POS, "bin": BIN, "cat": CAT}

@@ -350,7 +350,7 @@ __device__ __forceinline__ GemmGroup load_group(const GemmParams& p, int gi) {
 template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int WPE, bool DB, bool DMA, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     static_assert(!DMA || (DB && VEC), "the LDS-DMA path is the two-stage, 16-B aligned one");
-    static_assert(!SPLIT || (!DMA && !DB), "split mode converts in registers: single LDS stage");
+    static_assert(!SPLIT || !DMA, "split mode converts in registers");
     static_assert(WM * WN <= 8, "at most 8 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int LDS_A = SPLIT ? (A_KC ? BM * SPLIT_RS / 2 : 48 * BM) : (A_KC ? BM * (DMA ? 32 : 36) : 32 * BM);
@@ -463,7 +463,31 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                 }
         }
     };
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && DB) {
+        // two LDS stages, one barrier per K-tile: the next tile's registers are split and parked in the other stage
+        // in the shadow of this tile's MFMAs
+        if (kbeg < kend) {
+            la.load(g.A, p.lda, m0, Mrows, kbeg, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid, bidx);
+        }
+        la.store_split(ldsA, tid);
+        lb.store_split(ldsB, tid);
+        __syncthreads();
+        int cur = 0, k0 = kbeg;
+        for (; k0 + 32 < kend; k0 += 32) {
+            la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
+            lb.load(g.B, p.ldb, n0, p.N, k0 + 32, kend, tid, bidx);
+            compute_split(ldsA + cur * STAGE, ldsB + cur * STAGE);
+            la.store_split(ldsA + (cur ^ 1) * STAGE, tid);
+            lb.store_split(ldsB + (cur ^ 1) * STAGE, tid);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (k0 < kend) {
+            compute_split(ldsA + cur * STAGE, ldsB + cur * STAGE);
+            __syncthreads();
+        }
+    } else if constexpr (SPLIT) {
         if (kbeg < kend) {
             la.load(g.A, p.lda, m0, Mrows, kbeg, kend, tid, aidx);
             lb.load(g.B, p.ldb, n0, p.N, kbeg, kend, tid, bidx);
@@ -776,6 +800,7 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
         if (g_gemm_split > 0) {
             static const int st = [] { const char* f = getenv("SHIVAE_SPLIT_TILE"); return f ? atoi(f) : 0; }();
             if (st == 1) return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2, 2, false, false, true>(p, ngroups, stream);  // 4 waves of 64x64
+            if (st == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 2, true, false, true>(p, ngroups, stream);   // two LDS stages, 1 WG/CU
             return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false, false, true>(p, ngroups, stream);
         }
         // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands
