@@ -1049,10 +1049,9 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
     p->ws = static_cast<char*>(ws);
     p->params = params;
     p->grads = grads;
-    // Padding columns and the t=0 h_prev rows rely on the workspace starting at zero.  Cleared in pieces of 1 GiB
-    // (asynchronously, one wait at the end of bind): a single fill of the whole workspace -- 170 GB at cfg3 -- is one
-    // dispatch whose size does not fit 32 bits, and the only step of the set-up that differed between the runs
-    // that survived `rocprofv3 --pmc` and the one that did not.
+    // Padding columns and the t=0 h_prev rows rely on the workspace starting at zero.  Cleared in pieces of 1 GiB,
+    // asynchronously, with one wait at the end of bind (170 GB at cfg3 as ONE fill is a dispatch of its own kind; it
+    // was a suspect for the round-1 crash under `rocprofv3 --pmc` and turned out not to be the cause -- DESIGN.md s.4).
     for (size_t off = 0; off < p->ws_bytes; off += (size_t)1 << 30)
         SV_CHECK_HIP(hipMemsetAsync(p->ws + off, 0, std::min<size_t>((size_t)1 << 30, p->ws_bytes - off), nullptr));
     {
