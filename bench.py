@@ -67,7 +67,7 @@ def host_cores():
     return len(phys) or (os.cpu_count() or 1), aff
 
 
-def cpu_baseline(cfgname, types_list, H, Z, K, seconds=14.0):
+def cpu_baseline(cfgname, types_list, H, Z, K, seconds=12.0):
     """The numpy oracle (a port of the reference algorithm) timed on the host cores on a bounded sample."""
     import numpy as np
     from oracle import shivae_oracle as so
@@ -94,6 +94,26 @@ def cpu_baseline(cfgname, types_list, H, Z, K, seconds=14.0):
         if step >= 3 and time.time() > t_end:
             break
     dt = sorted(times)[len(times) // 2]
+    # SURVEY.md 8d's like-for-like figure: stock PyTorch-CPU ops arranged as the reference arranges them (Python loop
+    # over t, inside it a Python loop over the attribute decoders, autograd backward, clip_grad_norm_, Adam)
+    torch_loop = None
+    try:
+        from oracle import torch_cpu_step as tc
+        Pt = tc.make_params(so.init_params(types_list, H, Z, K, True, seed=0, dtype=np.float32))
+        opt = torch.optim.Adam(list(Pt.values()), lr=5e-3)
+        tt, t_end = [], time.time() + 0.6 * seconds
+        for _ in range(4):
+            t0 = time.time()
+            tc.train_step(Pt, opt, types_list, H, Z, K, x, mask, u, eps, 1.0, 3.0, True, 0.5)
+            tt.append(time.time() - t0)
+            if len(tt) >= 2 and time.time() > t_end:
+                break
+        torch_loop = {"value": Bc * Tc / min(tt[1:] or tt), "unit": "sequence-timesteps/s", "torch_threads": torch.get_num_threads(),
+                      "sample": "oracle/torch_cpu_step.py (fp32, reference-style loops, autograd), same model and "
+                                "B=%d T=%d, best of %d steps after one warm-up" % (Bc, Tc, max(1, len(tt) - 1))}
+        del Pt, opt
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        torch_loop = {"error": repr(e)}
     threads = None
     try:
         from threadpoolctl import threadpool_info
@@ -108,7 +128,8 @@ def cpu_baseline(cfgname, types_list, H, Z, K, seconds=14.0):
             "host_physical_cores": phys, "cpus_allowed": aff,
             "threads": "BLAS pool of %d threads (OMP_NUM_THREADS=%s)" % (threads, os.environ.get("OMP_NUM_THREADS", "unset")),
             "sample": "numpy oracle (fp32), %s model, B=%d T=%d, fwd+bwd+clip+Adam, median of %d steps"
-                      % (cfgname, Bc, Tc, len(times))}
+                      % (cfgname, Bc, Tc, len(times)),
+            "torch_cpu_reference_style": torch_loop}
 
 
 def pmc_traffic(cfgname, B, T, kernel):

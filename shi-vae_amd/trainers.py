@@ -2,8 +2,8 @@
 BaseTrainer / KL_Annealing) around the HIP step.  What is kept: constructor signature, ``train``,
 ``train_epoch``, ``valid_epoch``, ``load_checkpoint``, ``preprocess_batch``, the KL / temperature
 schedules, checkpoint dict layout ``{'state_dict','epoch','optimizer','params'}`` and the ';'-separated
-loss CSVs.  What is dropped on purpose: matplotlib plots and the imputation-error plots of
-``valid_epoch`` (SURVEY.md section 8f rows f2/f4 -- outside the accelerated path)."""
+loss CSVs, the imputation-error evaluation of ``valid_epoch`` (every ``args.plot_every`` epochs, result in
+``trainer.last_avg_error``).  What is dropped on purpose: the matplotlib plots."""
 import csv
 import os
 
@@ -204,7 +204,46 @@ class Trainer:
         epoch_loss = {k: float(np.mean(v)) for k, v in epoch_loss.items()}
         if epoch % self.print_every == 0:
             print(("Epoch (valid): {}/{}\n" + self.print_str).format(epoch, self.n_epochs, **epoch_loss))
+        plot_every = int(getattr(self.args, "plot_every", 0) or 0)
+        if plot_every > 0 and epoch % plot_every == 0:
+            self.last_avg_error = self.imputation_error(valid_loader)
         return self.early_stopping.stop(epoch_loss['n_elbo']), epoch_loss
+
+    def imputation_error(self, loader):
+        """trainers.py:286-333 without the plots: reconstruct the evaluation view of the loader's dataset
+        (data with the artificial mask applied), de-normalise, and score the artificially removed entries ->
+        (error_miss, corr_miss) dicts per attribute (lib/loss.py:71-201).  None if the dataset has no evaluation
+        view or there is no scaler."""
+        from .metrics import compute_avg_error
+        ds = getattr(loader, "dataset", None)
+        if ds is None or not hasattr(ds, "set_eval") or self.scaler is None:
+            return None
+        was_training = self.model.training
+        self.model.eval()
+        ds.set_eval(True)
+        try:
+            data_hat, masks, fulls, arts = [], [], [], []
+            with torch.no_grad():
+                for data, mask, data_full, mask_artificial, _attrs in loader:
+                    data, mask = self.preprocess_batch(data, mask)
+                    data_zf = utils.zero_fill(data, mask)
+                    (_likes, x_hat), _lat = self.model.reconstruction(data_zf, temp=self.temp)
+                    data_hat.append(x_hat)
+                    masks.append(mask)
+                    fulls.append(np.asarray(data_full))
+                    arts.append(np.asarray(mask_artificial))
+            data_hat = torch.cat(data_hat, dim=1)                      # [T, sum B, X]  (np.hstack in the reference)
+            mask = torch.cat(masks, dim=1)
+            data_full, mask_artificial = np.vstack(fulls), np.vstack(arts).astype(bool)
+            data_hat_denorm, mask = self.scaler.inverse_transform(data_hat, mask=mask, transpose=True)
+            real_mask = mask_artificial ^ mask.astype(bool)
+            data_full_zf = np.where(real_mask, np.zeros_like(data_full), data_full)
+            _, error_miss, _, corr_miss = compute_avg_error(data_full_zf, data_hat_denorm, mask_artificial,
+                                                            self.model.types_list, img_path=self.result_dir)
+        finally:
+            ds.set_eval(False)
+            self.model.train(was_training)
+        return error_miss, corr_miss
 
     def train(self, train_loader, valid_loader):
         """trainers.py:118-179."""

@@ -92,3 +92,9 @@ def test_gpu_main_hmm_flow(tmp_path):
     assert data_hat.shape == d["X"][te].shape
     _, err, _, corr = metrics.compute_avg_error(d["X"][te], data_hat, mask[te].astype(int), tl)
     assert all(np.isfinite(v) for v in err.values()) and all(np.isfinite(v) for v in corr.values())
+    # the same evaluation inside valid_epoch (trainers.py:286-333), every args.plot_every epochs
+    args.plot_every = 1
+    stop, va = tr.valid_epoch(mk(d["val_index"]), 7)
+    assert np.isfinite(va["n_elbo"]) and tr.last_avg_error is not None
+    err_v, corr_v = tr.last_avg_error
+    assert set(err_v) == {t["name"] for t in tl} and all(np.isfinite(v) for v in err_v.values())

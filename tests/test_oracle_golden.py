@@ -113,3 +113,22 @@ def test_oracle_numerical_gradient():
             vals.append(mm.forward(g["x"], g["mask"], g["u"], g["eps"], cfg["beta"], cfg["temp"])["losses"]["n_elbo"])
         fd = (vals[0] - vals[1]) / (2 * h)
         assert abs(fd - G[k][idx]) < 1e-5 * max(1.0, abs(fd)), (k, idx, fd, G[k][idx])
+
+
+@pytest.mark.parametrize("name", ["tiny_all", "tiny_fixedstd", "cfg2like"])
+def test_torch_cpu_restatement_matches_reference(name):
+    """oracle/torch_cpu_step.py (the like-for-like CPU baseline of bench.py) against the reference's golden losses,
+    gradients, gradient norm and post-Adam parameters."""
+    import torch
+    from oracle import torch_cpu_step as tc
+    g, cfg, sd = _golden.load(name)
+    P = tc.make_params(sd)
+    opt = torch.optim.Adam(list(P.values()), lr=5e-3)
+    losses, gn = tc.train_step(P, opt, cfg["types_list"], cfg["H"], cfg["Z"], cfg["K"], g["x"], g["mask"], g["u"], g["eps"],
+                               cfg["beta"], cfg["temp"], cfg["learn_std"], clip=0.5)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), g["loss/" + k], rtol=2e-5, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=1e-4)
+    for k, p in P.items():
+        # (fp32 against fp32 with another summation order; an Adam step moves a parameter by ~lr = 5e-3)
+        assert np.abs(p.detach().numpy() - g["adam1/" + k]).max() <= 1e-5, k
