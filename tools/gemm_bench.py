@@ -42,5 +42,36 @@ def main():
     run(2, 256, 512, R, 65536 + 64, 131072 + 64, 512, epi=32, splitk=8, tag="TN wL1 padded ld")
     run(2, 4096, 4096, 4096, 4096, 4096, 4096, tag="TN 4096^3")
 
+def long_k():
+    """long-K and wide-ld shapes (formerly gemm_bench2.py)"""
+    R = 16384
+    run(1, R, 512, 8192, 8192, 512, 512, tag="NN K=8192 lda=8192")
+    run(1, R, 512, 8192, 131136, 512, 512, tag="NN K=8192 lda=131136")
+    run(1, R, 512, 8192, 8192, 528, 512, tag="NN K=8192 ldb=528")
+    run(0, R, 512, 8192, 8192, 8192, 512, tag="NT K=8192")
+    run(0, R, 512, 8192, 131136, 8192, 512, tag="NT K=8192 lda=131136")
+    run(2, 512, 512, R, 512, 512, 512, epi=32, splitk=16, tag="TN K=16384 splitk16")
+    run(1, R, 2048, 2048, 2048, 2048, 2048, tag="NN 16384x2048x2048")
+    run(0, R, 2048, 2048, 2048, 2048, 2048, tag="NT 16384x2048x2048")
+
+
+def layer0():
+    """layer-0 forward shapes: wide N, short K (formerly gemm_bench3.py)"""
+    R = 16640
+    for n in (32768, 131072):
+        run(0, R, n, 528, 528, 528, n + 64, tag="NT N=%d" % n)
+        run(0, R, n, 528, 528, 528, n + 64, epi=3, tag="NT N=%d bias+relu" % n)
+
+
+def one(layout, M, Nn, K):
+    """one shape, three launches, for rocprofv3 --pmc passes (formerly gemm_one.py)"""
+    run(layout, M, Nn, K, K if layout != 2 else M, K if layout == 0 else Nn, Nn, tag="one", iters=3, warm=0)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    what = sys.argv[1] if len(sys.argv) > 1 else "main"
+    if what == "one":
+        one(*(int(v) for v in sys.argv[2:6]))
+    else:
+        {"main": main, "long_k": long_k, "layer0": layer0}[what]()
