@@ -811,7 +811,9 @@ static int phase_scan_bwd(shivae_plan* p, const float* x, const float* u, const 
     float *emb = p->wsf("emb"), *p1 = p->wsf("p1"), *phx = p->wsf("phx");
     ScanArgs sa = scan_args(p, u, eps, temp);
     {
-        prof_begin(PROF_SCAN_BWD, 2.0 * scan_flops(p), s);
+        // (the reverse chain multiplies by the transposes of the forward chain's matrices: the same MFMA work.  The
+        // other half of "backward = 2 x forward", the weight gradients, are the batched TN GEMMs below.)
+        prof_begin(PROF_SCAN_BWD, scan_flops(p), s);
         SV_TRY(launch_scan(sa, true, s));
         prof_end(s);
         // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics)

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
 
     int cur = 0;
     for (int t = 0; t < a.T; ++t) {
-        const size_t row = (size_t)t * B + (live ? bj : 0);
+        size_t row = (size_t)t * B + (live ? bj : 0);
+        int ln = lane;
+        // (opaque to the optimiser: otherwise the per-lane addresses of every record array and of every weight image
+        // are kept in registers across the whole time loop, two each, and the kernel spills)
+        asm volatile("" : "+v"(row), "+v"(ln));
+        const int j = ln & 15, q = ln >> 4;
         const float* h = cur ? hb1 : hb0;
         float* hn = cur ? hb0 : hb1;
 
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             f32x4 acc[MAXS];
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) { acc[s] = zero4; e1acc[s] = zero4; }
-            mma_acc<MAXS>(acc, Wb + a.w.xsh, HT, own, h, lane);
+            mma_acc<MAXS>(acc, Wb + a.w.xsh, HT, own, h, ln);
 #pragma unroll
             for (int s = 0; s < MAXS; ++s)
                 if (ownok[s]) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                     st4(bufA + qidx(own[s], q, j), v);
                     if (live) stg4(a.as_ + row * Hp + own[s] * 16 + 4 * q, v);
                 }
-            mma_acc<MAXS>(e1acc, Wb + a.w.e0h, HT, own, h, lane);
+            mma_acc<MAXS>(e1acc, Wb + a.w.e0h, HT, own, h, ln);
         }
         __syncthreads();
         // P1: s logits = LeakyReLU(Wxs2 a_s + b) (encoders.py:56-57); s_probs = softmax(logits),
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             if (wid == 0) {
                 const int nt0[1] = {0};
                 f32x4 lg[1] = {zero4};
-                mma_acc<1>(lg, Wb + a.w.lg, HT, nt0, bufA, lane);
+                mma_acc<1>(lg, Wb + a.w.lg, HT, nt0, bufA, ln);
                 const f32x4 bl = ld4(Wb + a.w.b_lg + 4 * q);
                 float l[4], y[4], m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
         } else {
             {
                 const Src src[1] = {{Wb + a.w.lg, bufA, HT}};
-                layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
+                layer<1>(KT, src, wid, NW, ln, [&](int nt, f32x4 v) {
                     v += ld4(Wb + a.w.b_lg + nt * 16 + 4 * q);
                     st4(lgbuf + qidx(nt, q, j), f32x4{sv_leaky(v[0]), sv_leaky(v[1]), sv_leaky(v[2]), sv_leaky(v[3])});
                 });
@@ -299,12 +304,12 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             const int nt[4] = {own[s], HT + own[s], 2 * HT + own[s], 3 * HT + own[s]};
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) g4[s][gi] = zero4;
-            if (ownok[s]) mma_acc<4>(g4[s], Wb + a.w.hh, HT, nt, h, lane);
+            if (ownok[s]) mma_acc<4>(g4[s], Wb + a.w.hh, HT, nt, h, ln);
         }
         __syncthreads();
         // P2: e1 = relu(ex_pre + We0[:, H:H+K] s + We0[:, H+K:] h)    encoders.py:91 (phi_x part hoisted)
         {
-            mma_acc<MAXS>(e1acc, Wb + a.w.e0s, KT, own, sbuf, lane);
+            mma_acc<MAXS>(e1acc, Wb + a.w.e0s, KT, own, sbuf, ln);
 #pragma unroll
             for (int s = 0; s < MAXS; ++s)
                 if (ownok[s]) {
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             f32x4 acc[MAXS];
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
-            mma_acc<MAXS>(acc, Wb + a.w.e2, HT, own, bufB, lane);
+            mma_acc<MAXS>(acc, Wb + a.w.e2, HT, own, bufB, ln);
 #pragma unroll
             for (int s = 0; s < MAXS; ++s)
                 if (ownok[s]) {
@@ -334,8 +339,8 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
         for (int zt = wid; zt < ZT; zt += NW) {
             const int nt[1] = {zt};
             f32x4 am[1] = {zero4}, as[1] = {zero4};
-            mma_acc<1>(am, Wb + a.w.mu, HT, nt, bufA, lane);
-            mma_acc<1>(as, Wb + a.w.sd, HT, nt, bufA, lane);
+            mma_acc<1>(am, Wb + a.w.mu, HT, nt, bufA, ln);
+            mma_acc<1>(as, Wb + a.w.sd, HT, nt, bufA, ln);
             const int n = zt * 16 + 4 * q;
             const f32x4 mu = am[0] + ld4(Wb + a.w.b_mu + n);
             const f32x4 sp = as[0] + ld4(Wb + a.w.b_sd + n);
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             f32x4 acc[MAXS];
 #pragma unroll
             for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
-            mma_acc<MAXS>(acc, Wb + a.w.pz, ZT, own, zbuf, lane);
+            mma_acc<MAXS>(acc, Wb + a.w.pz, ZT, own, zbuf, ln);
 #pragma unroll
             for (int s = 0; s < MAXS; ++s)
                 if (ownok[s]) {
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             if (ownok[s]) {
                 const int ht = own[s];
                 const int nt[4] = {ht, HT + ht, 2 * HT + ht, 3 * HT + ht};
-                mma_acc<4>(g4[s], Wb + a.w.ih, HT, nt, bufB, lane);
+                mma_acc<4>(g4[s], Wb + a.w.ih, HT, nt, bufB, ln);
                 const int n = ht * 16 + 4 * q;
 #pragma unroll
                 for (int gidx = 0; gidx < 4; ++gidx) g4[s][gidx] += ld4(Wb + a.w.b_g + gidx * Hp + n);
@@ -590,27 +595,75 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
 
     for (int i = tid; i < Hp * 16; i += blockDim.x) dhb[i] = 0.f;
     f32x4 dcreg[MAXS], dhacc[MAXS];
+    int own[MAXS];      // owned hidden tile (clamped), valid if ownok
+    bool ownok[MAXS];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) dcreg[s] = zero4;
+    for (int s = 0; s < MAXS; ++s) {
+        dcreg[s] = zero4;
+        ownok[s] = wid + s * NW < HT;
+        own[s] = ownok[s] ? wid + s * NW : 0;
+    }
     __syncthreads();
 
+    // Every record this chain reads back (gates, cell states, the ReLU gates of the four hidden layers, the
+    // gradients arriving from the decoder / prior / KL terms) is independent of the recurrence: the cell records of
+    // step t-1 are requested while step t runs, everything else at the top of its step, so that no HBM round trip
+    // sits between two phases of the serial chain.
+    f32x4 c_gi[MAXS], c_gf[MAXS], c_gg[MAXS], c_go[MAXS], c_cn[MAXS], c_cp[MAXS];
+    auto load_cell = [&](int t) {
+        size_t row = (size_t)t * B + (live ? bj : 0);
+        asm volatile("" : "+v"(row));
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            c_gi[s] = c_gf[s] = c_gg[s] = c_go[s] = c_cn[s] = c_cp[s] = zero4;
+            if (live && ownok[s]) {
+                const int n = own[s] * 16 + 4 * q;
+                const float* gp = a.gates + row * 4 * Hp + n;
+                c_gi[s] = ldg4(gp); c_gf[s] = ldg4(gp + Hp); c_gg[s] = ldg4(gp + 2 * Hp); c_go[s] = ldg4(gp + 3 * Hp);
+                c_cn[s] = ldg4(a.cnew + row * Hp + n);
+                if (t > 0) c_cp[s] = ldg4(a.cnew + (row - B) * Hp + n);
+            }
+        }
+    };
+    load_cell(a.T - 1);
+
     for (int t = a.T - 1; t >= 0; --t) {
-        const size_t row = (size_t)t * B + (live ? bj : 0);
+        size_t row = (size_t)t * B + (live ? bj : 0);
+        // (opaque to the optimiser: otherwise every record array gets a strength-reduced per-lane pointer of its own,
+        // two registers each for ~25 arrays, and the kernel spills)
+        asm volatile("" : "+v"(row));
+        int ln = lane;  // (same for the per-lane weight addresses of the ten mma_acc call sites)
+        asm volatile("" : "+v"(ln));
+        const int j = ln & 15, q = ln >> 4;  // (shadow the kernel-scope copies: LDS / record offsets are recomputed, not kept)
+        f32x4 g_pz[MAXS], d_pz[MAXS], g_e2[MAXS], g_e1[MAXS], g_as[MAXS], d_hx[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const bool ld = live && ownok[s];
+            const int n = own[s] * 16 + 4 * q;
+            g_pz[s] = ld ? ldg4(a.emb + row * Ep + n) : zero4;
+            d_pz[s] = ld ? ldg4(a.d_emb + row * Ep + n) : zero4;
+            g_e2[s] = ld ? ldg4(a.e2 + row * Hp + n) : zero4;
+            g_e1[s] = ld ? ldg4(a.e1 + row * Hp + n) : zero4;
+        }  // (g_as, d_hx: requested after B2, in the registers g_pz / d_pz leave)
+        f32x4 z_dmu = zero4, z_dsd = zero4, z_sd = zero4, z_eps = zero4;  // z tile wid (further tiles load in place)
+        if (wid < ZT && live) {
+            const int n = wid * 16 + 4 * q;
+            z_dmu = ldg4(a.dmu_ext + row * Zp + n);
+            z_dsd = ldg4(a.dsd_ext + row * Zp + n);
+            z_sd = ldg4(a.sd + row * Zp + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < a.Z) z_eps[r] = a.eps[row * a.Z + n + r];
+        }
+
         // B1: LSTM cell backward on the owned hidden units (elementwise, registers)
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
-            const int ht = wid + s * NW;
             dhacc[s] = zero4;
-            if (ht < HT) {
-                const int n = ht * 16 + 4 * q;
+            if (ownok[s]) {
+                const int ht = own[s], n = ht * 16 + 4 * q;
                 const f32x4 dh = ld4(dhb + qidx(ht, q, j));
-                f32x4 gi = zero4, gf = zero4, gg = zero4, go = zero4, cn = zero4, cp = zero4;
-                if (live) {
-                    const float* gp = a.gates + row * 4 * Hp + n;
-                    gi = ld4(gp); gf = ld4(gp + Hp); gg = ld4(gp + 2 * Hp); go = ld4(gp + 3 * Hp);
-                    cn = ldg4(a.cnew + row * Hp + n);
-                    if (t > 0) cp = ldg4(a.cnew + (row - B) * Hp + n);
-                }
+                const f32x4 gi = c_gi[s], gf = c_gf[s], gg = c_gg[s], go = c_go[s], cn = c_cn[s], cp = c_cp[s];
                 f32x4 di, df, dg, dO, dc = dcreg[s];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -633,46 +686,53 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 }
             }
         }
+        if (t > 0) load_cell(t - 1);  // in flight for the rest of this step
         __syncthreads();
         // B2: dphi_z = Wih^T dgates + (decoder's dphi_z); through ReLU.   dh_prev += Whh^T dgates
         {
-            const Src src[1] = {{Wb + a.w.t_ih, dgb, 4 * HT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                f32x4 pz = zero4;
-                if (live) { v += ldg4(a.d_emb + row * Ep + n); pz = ldg4(a.emb + row * Ep + n); }
-                v = gate4(v, pz);
-                st4(bufB + qidx(nt, q, j), v);
-                if (live) stg4(a.d_phiz_pre + row * Hp + n, v);
-            });
+            f32x4 acc[MAXS];
 #pragma unroll
-            for (int s = 0; s < MAXS; ++s) {
-                const int ht = wid + s * NW;
-                if (ht < HT) {
-                    const int nt[1] = {ht};
-                    f32x4 acc[1] = {dhacc[s]};
-                    mma_acc<1>(acc, Wb + a.w.t_hh, 4 * HT, nt, dgb, lane);
-                    dhacc[s] = acc[0];
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.t_ih, 4 * HT, own, dgb, ln);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const int n = own[s] * 16 + 4 * q;
+                    const f32x4 v = gate4(acc[s] + d_pz[s], g_pz[s]);
+                    st4(bufB + qidx(own[s], q, j), v);
+                    if (live) stg4(a.d_phiz_pre + row * Hp + n, v);
                 }
-            }
+            mma_acc<MAXS>(dhacc, Wb + a.w.t_hh, 4 * HT, own, dgb, ln);
+        }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const bool ld = live && ownok[s];
+            const int n = own[s] * 16 + 4 * q;
+            g_as[s] = ld ? ldg4(a.as_ + row * Hp + n) : zero4;
+            d_hx[s] = ld ? ldg4(a.d_emb + row * Ep + Hp + Kp + n) : zero4;
         }
         __syncthreads();
         // B3: dz = Wz^T dphi_z_pre; dmu = dz + dKL/dmu; dstd_pre = (dz*eps + dKL/dstd) * softplus'
         for (int zt = wid; zt < ZT; zt += NW) {
             const int nt[1] = {zt};
             f32x4 acc[1] = {zero4};
-            mma_acc<1>(acc, Wb + a.w.t_pz, HT, nt, bufB, lane);
+            mma_acc<1>(acc, Wb + a.w.t_pz, HT, nt, bufB, ln);
             const int n = zt * 16 + 4 * q;
-            f32x4 dmu = acc[0], dsd = zero4;
-            if (live) {
-                dmu += ldg4(a.dmu_ext + row * Zp + n);
-                const f32x4 de = ldg4(a.dsd_ext + row * Zp + n), sd = ldg4(a.sd + row * Zp + n);
+            f32x4 xm = z_dmu, xs = z_dsd, sd = z_sd, ep = z_eps;
+            if (zt != wid) {
+                xm = xs = sd = ep = zero4;
+                if (live) {
+                    xm = ldg4(a.dmu_ext + row * Zp + n); xs = ldg4(a.dsd_ext + row * Zp + n); sd = ldg4(a.sd + row * Zp + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = (n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
-                    dsd[r] = (acc[0][r] * e + de[r]) * sv_softplus_grad_from_out(sd[r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < a.Z) ep[r] = a.eps[row * a.Z + n + r];
                 }
             }
+            f32x4 dmu = acc[0] + xm, dsd = zero4;
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsd[r] = (acc[0][r] * ep[r] + xs[r]) * sv_softplus_grad_from_out(sd[r]);
+            } else dmu = acc[0];
             st4(dmub + qidx(zt, q, j), dmu);
             st4(dsdb + qidx(zt, q, j), dsd);
             if (live) {
@@ -680,92 +740,122 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 stg4(a.d_sd_pre + row * Zp + n, dsd);
             }
         }
+        f32x4 k_s = zero4, k_ds = zero4, k_kl = zero4, k_lg = zero4;  // wave 0, K <= 16: the s row and what reaches it
+        if (wid == 0 && KT == 1 && live) {  // (requested two phases ahead of B6, in the registers the z operands leave)
+            k_s = ldg4(a.emb + row * Ep + Hp + 4 * q);
+            k_ds = ldg4(a.d_emb + row * Ep + Hp + 4 * q);
+            k_kl = ldg4(a.dlg_kl + row * Kp + 4 * q);
+            k_lg = ldg4(a.logits + row * Kp + 4 * q);
+        }
         __syncthreads();
         // B4: de2 = Wm^T dmu + Ws^T dstd_pre, through ReLU
         {
-            const Src src[2] = {{Wb + a.w.t_mu, dmub, ZT}, {Wb + a.w.t_sd, dsdb, ZT}};
-            layer<2>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ldg4(a.e2 + row * Hp + n) : zero4);
-                st4(bufA + qidx(nt, q, j), v);
-                if (live) stg4(a.d_e2_pre + row * Hp + n, v);
-            });
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.t_mu, ZT, own, dmub, ln);
+            mma_acc<MAXS>(acc, Wb + a.w.t_sd, ZT, own, dsdb, ln);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const f32x4 v = gate4(acc[s], g_e2[s]);
+                    st4(bufA + qidx(own[s], q, j), v);
+                    if (live) stg4(a.d_e2_pre + row * Hp + own[s] * 16 + 4 * q, v);
+                }
         }
         __syncthreads();
         // B5: de1 = We2^T de2_pre, through ReLU
         {
-            const Src src[1] = {{Wb + a.w.t_e2, bufA, HT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ldg4(a.e1 + row * Hp + n) : zero4);
-                st4(bufB + qidx(nt, q, j), v);
-                if (live) stg4(a.d_e1_pre + row * Hp + n, v);
-            });
-        }
-        __syncthreads();
-        // B6: ds = We0_s^T de1_pre + (decoder/prior ds);   dh_prev += We0_h^T de1_pre
-        {
-            const Src src[1] = {{Wb + a.w.t_e0s, bufB, HT}};
-            layer<1>(KT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                if (live) v += ldg4(a.d_emb + row * Ep + Hp + nt * 16 + 4 * q);
-                st4(dsb + qidx(nt, q, j), v);
-            });
+            f32x4 acc[MAXS];
 #pragma unroll
-            for (int s = 0; s < MAXS; ++s) {
-                const int ht = wid + s * NW;
-                if (ht < HT) {
-                    const int nt[1] = {ht};
-                    f32x4 acc[1] = {dhacc[s]};
-                    mma_acc<1>(acc, Wb + a.w.t_e0h, HT, nt, bufB, lane);
-                    dhacc[s] = acc[0];
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.t_e2, HT, own, bufA, ln);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const f32x4 v = gate4(acc[s], g_e1[s]);
+                    st4(bufB + qidx(own[s], q, j), v);
+                    if (live) stg4(a.d_e1_pre + row * Hp + own[s] * 16 + 4 * q, v);
                 }
-            }
         }
         __syncthreads();
-        // B6b: Gumbel-softmax backward + KL(s) gradient, through LeakyReLU
-        if (tid < 16) {
-            const int jj = tid, bb = blockIdx.x * 16 + jj;
-            const bool lv = bb < B;
-            const size_t r = (size_t)t * B + (lv ? bb : 0);
-            float dot = 0.f;
-            for (int k = 0; k < a.K; ++k)
-                dot += (lv ? a.emb[r * Ep + Hp + k] : 0.f) * dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-            for (int k = 0; k < Kp; ++k) {
-                float dl = 0.f;
-                if (k < a.K && lv) {
-                    const float sv = a.emb[r * Ep + Hp + k];
-                    const float ds = dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                    dl = sv * (ds - dot) / a.temp + a.dlg_kl[r * Kp + k];
-                    dl *= a.logits[r * Kp + k] > 0.f ? 1.f : 0.01f;
-                    a.d_lg_pre[r * Kp + k] = dl;
+        // B6: ds = We0_s^T de1_pre + (decoder/prior ds), then the Gumbel-softmax backward + the KL(s) gradient, through
+        //     LeakyReLU;   dh_prev += We0_h^T de1_pre
+        if (KT == 1) {
+            // K <= 16: wave 0 holds the ds tile with k = 4q+r in lane (q, j): the softmax backward is an in-lane sum
+            // over r plus two xor-shuffles over q, on operands requested at the top of the step
+            if (wid == 0) {
+                const int nt0[1] = {0};
+                f32x4 ds[1] = {zero4};
+                mma_acc<1>(ds, Wb + a.w.t_e0s, HT, nt0, bufB, ln);
+                ds[0] += k_ds;
+                float dot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot += k_s[r] * ds[0][r];
+                dot += __shfl_xor(dot, 16);
+                dot += __shfl_xor(dot, 32);
+                f32x4 dl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = k_s[r] * (ds[0][r] - dot) / a.temp + k_kl[r];
+                    v *= k_lg[r] > 0.f ? 1.f : 0.01f;
+                    dl[r] = (4 * q + r < a.K && live) ? v : 0.f;
                 }
-                dlgb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = dl;
+                st4(dlgb + qidx(0, q, j), dl);
+                if (live) stg4(a.d_lg_pre + row * Kp + 4 * q, dl);
+            }
+            mma_acc<MAXS>(dhacc, Wb + a.w.t_e0h, HT, own, bufB, ln);
+        } else {
+            {
+                const Src src[1] = {{Wb + a.w.t_e0s, bufB, HT}};
+                layer<1>(KT, src, wid, NW, ln, [&](int nt, f32x4 v) {
+                    if (live) v += ldg4(a.d_emb + row * Ep + Hp + nt * 16 + 4 * q);
+                    st4(dsb + qidx(nt, q, j), v);
+                });
+            }
+            mma_acc<MAXS>(dhacc, Wb + a.w.t_e0h, HT, own, bufB, ln);
+            __syncthreads();
+            if (tid < 16) {
+                const int jj = tid, bb = blockIdx.x * 16 + jj;
+                const bool lv = bb < B;
+                const size_t r = (size_t)t * B + (lv ? bb : 0);
+                float dot = 0.f;
+                for (int k = 0; k < a.K; ++k)
+                    dot += (lv ? a.emb[r * Ep + Hp + k] : 0.f) * dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                for (int k = 0; k < Kp; ++k) {
+                    float dl = 0.f;
+                    if (k < a.K && lv) {
+                        const float sv = a.emb[r * Ep + Hp + k];
+                        const float ds = dsb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
+                        dl = sv * (ds - dot) / a.temp + a.dlg_kl[r * Kp + k];
+                        dl *= a.logits[r * Kp + k] > 0.f ? 1.f : 0.01f;
+                        a.d_lg_pre[r * Kp + k] = dl;
+                    }
+                    dlgb[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)] = dl;
+                }
             }
         }
         __syncthreads();
         // B7: da_s = Wxs2^T dlogits_pre, through ReLU
         {
-            const Src src[1] = {{Wb + a.w.t_lg, dlgb, KT}};
-            layer<1>(HT, src, wid, NW, lane, [&](int nt, f32x4 v) {
-                const int n = nt * 16 + 4 * q;
-                v = gate4(v, live ? ldg4(a.as_ + row * Hp + n) : zero4);
-                st4(bufA + qidx(nt, q, j), v);
-                if (live) stg4(a.d_as_pre + row * Hp + n, v);
-            });
+            f32x4 acc[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[s] = zero4;
+            mma_acc<MAXS>(acc, Wb + a.w.t_lg, KT, own, dlgb, ln);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (ownok[s]) {
+                    const f32x4 v = gate4(acc[s], g_as[s]);
+                    st4(bufA + qidx(own[s], q, j), v);
+                    if (live) stg4(a.d_as_pre + row * Hp + own[s] * 16 + 4 * q, v);
+                }
         }
         __syncthreads();
         // B8: dh_{t-1} = Whh^T.. + We0_h^T.. + Wxs0_h^T das_pre + (decoder/prior dh_prev)
+        mma_acc<MAXS>(dhacc, Wb + a.w.t_xsh, HT, own, bufA, ln);
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const int ht = wid + s * NW;
-            if (ht < HT) {
-                const int nt[1] = {ht};
-                f32x4 acc[1] = {dhacc[s]};
-                mma_acc<1>(acc, Wb + a.w.t_xsh, HT, nt, bufA, lane);
-                if (live) acc[0] += ldg4(a.d_emb + row * Ep + Hp + Kp + ht * 16 + 4 * q);
-                st4(dhb + qidx(ht, q, j), acc[0]);
-            }
-        }
+        for (int s = 0; s < MAXS; ++s)
+            if (ownok[s]) st4(dhb + qidx(own[s], q, j), dhacc[s] + d_hx[s]);
         __syncthreads();
     }
 }
@@ -818,11 +908,11 @@ static int scan_geometry(const ScanArgs& a, int& nw, int& maxs, bool bwd = false
     while (nw * 2 <= HT && nw < 16) nw *= 2;
     static const int force = [] { const char* f = getenv("SHIVAE_SCAN_WAVES"); return f ? atoi(f) : 0; }();
     if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) nw = std::min(nw, force);
-    // The forward chain runs best on 8 waves (256 registers each: the pipelined weight fetch and the gate
-    // accumulators stay in registers; with 16 waves at 128 registers it spilled ~100 of them): 80.3 ms against 90.0 ms
-    // for B=4096, T=1000 at H=256.  The reverse chain has more independent MFMA work per phase and wants the 16 waves
-    // (101.9 ms against 131.8 ms).
-    else if (!bwd) nw = std::min(nw, 8);
+    // Both chains run best on 8 waves of up to 256 registers (B=4096, T=1000, H=256: forward 79.1 ms against 82.6 ms
+    // on 16 waves, backward 93.2 against 104.3): with 128 registers per wave the prefetched records and the pipelined
+    // weight fetch spill.
+    else nw = std::min(nw, 8);
+    (void)bwd;
     const int need = ceil_div(HT, nw);
     maxs = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
     SV_REQUIRE(need <= 8, "scan: h_dim %d too large for the register-resident cell", a.H);
