@@ -515,7 +515,13 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
     }
     if (epi == 0 && K >= 8192) {
         // long K but too few output tiles to fill 256 CUs x 4 blocks: zero C, split K, accumulate atomically
-        const int sk = splitk_fill(M, N, K, 4096);
+        int sk = splitk_fill(M, N, K, 4096);
+        // Very long K (the layer-0 input gradient, K = D*2H = 131072): the column tiles that share a row slab of A
+        // stream 67 MB of it each; started together they drift apart further than an L2 holds, and the slab is
+        // fetched once per column tile (measured 3.3x the operand's bytes).  Shorter K ranges keep the siblings
+        // together (B=256, T=100 chunk: 27.7 -> 26.2 ms for this GEMM; SHIVAE_LONGK_CHUNK=0 restores one K range).
+        static const int long_k_chunk = [] { const char* f = getenv("SHIVAE_LONGK_CHUNK"); return f ? atoi(f) : 16384; }();
+        if (long_k_chunk > 0 && K >= 4 * long_k_chunk) sk = std::max(sk, std::min(64, K / long_k_chunk));
         if (sk > 1) {
             SV_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
             d.epi = EPI_ATOMIC;
