@@ -130,6 +130,10 @@ int shivae_plan_param_info(const shivae_plan* plan, int tensor_id, int attr, int
 int shivae_plan_x_dim(const shivae_plan* plan);
 int shivae_plan_p_dim(const shivae_plan* plan);
 int shivae_plan_chunk_rows(const shivae_plan* plan);
+/* Observed fraction (1 - missing rate of base_missvae.py:271-285's mask) of the first row chunk this plan trained
+ * on, which picks the form of the decoder's layer-0 input gradient (SHIVAE_DEMB); < 0 before the
+ * first training step or when SHIVAE_DEMB forces a form.  No counterpart in the reference. */
+float shivae_plan_observed_fraction(const shivae_plan* plan);
 
 size_t shivae_plan_workspace_bytes(const shivae_plan* plan);
 /* attach caller-owned device memory: workspace (>= workspace_bytes, 256-B aligned; it is zeroed

@@ -29,7 +29,7 @@ EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 1
 # every symbol include/shivae_hip.h declares
 SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_plan_destroy",
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
-           "shivae_plan_chunk_rows", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
+           "shivae_plan_chunk_rows", "shivae_plan_observed_fraction", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
            "shivae_set_gemm_split", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
            "shivae_allreduce_grads",
@@ -73,6 +73,8 @@ def lib():
     L.shivae_plan_param_info.argtypes = [vp, ci, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)]
     for f in ("shivae_plan_x_dim", "shivae_plan_p_dim", "shivae_plan_chunk_rows"):
         getattr(L, f).argtypes = [vp]
+    L.shivae_plan_observed_fraction.argtypes = [vp]
+    L.shivae_plan_observed_fraction.restype = cf
     L.shivae_plan_workspace_bytes.argtypes = [vp]
     L.shivae_plan_workspace_bytes.restype = C.c_size_t
     L.shivae_plan_bind.argtypes = [vp, vp, C.c_size_t, vp, vp]
@@ -161,6 +163,10 @@ class Plan:
     @property
     def chunk_rows(self):
         return int(lib().shivae_plan_chunk_rows(self.h))
+
+    @property
+    def observed_fraction(self):
+        return float(lib().shivae_plan_observed_fraction(self.h))
 
     @property
     def workspace_bytes(self):

@@ -122,6 +122,9 @@ struct shivae_plan {
     int cnt_slots = 0, cnt_next = 0;
     // grouped-GEMM tables
     GroupTable b_l0_w, b_l0_wr;  // layer-0 weight gradient per attribute (ragged steps): main columns + the E % 128 remainder
+    GroupTable b_l0_d, b_l0_dr;  // layer-0 input gradient per attribute over its observed rows, added into the chunk's rows
+    int demb_mode = 2;           // SHIVAE_DEMB: 0 "dense" (one GEMM over all attributes' column blocks), 1 "compact", 2 "auto"
+    float obs_frac = -1.f;       // auto: observed fraction of the first row chunk this plan trained on (< 0: not seen yet)
     int l0_nmain = 0;
     GroupTable f_l0, f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
     int compact = 1;  // mask-aware decoder in training steps (SHIVAE_COMPACT=0: dense)
@@ -370,7 +373,8 @@ static int build_tables(shivae_plan* p) {
     int* rowidx = reinterpret_cast<int*>(p->wsf("rowidx"));
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     const float* embc = p->wsf("embc");
-    std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, wl1, dl1, wl2, dl2, wh0, dh0;
+    std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, dl0, dl0r, wl1, dl1, wl2, dl2, wh0, dh0;
+    float* dembc = p->wsf("dembc");
     {
         // a few columns past a multiple of 128 (E = 528) go to a skinny launch of their own, as in gemm1
         const int rem = p->E % 128;
@@ -395,16 +399,22 @@ static int build_tables(shivae_plan* p) {
         all.push_back(d);
         // trunk (decoders.py:60-66).  Layer 0 as a group: the shared input gathered through the attribute's rows.
         fl0.push_back(G(embc, PA(SHIVAE_P_DEC0_W, d), a0d, PA(SHIVAE_P_DEC0_B, d), nullptr, nullptr, list));
-        // its weight gradient: da0 sits in chunk rows (see dl1), so both operands come through the row list
+        // its weight gradient: the shared input comes through the row list (bidx); da0 too (aidx) when it sits in
+        // chunk rows (SHIVAE_DEMB=dense, see dl1)
         wl0.push_back(G(da0d, embc, GA(SHIVAE_P_DEC0_W, d), nullptr, nullptr, nullptr, list, list));
         if (p->l0_nmain < p->E)
             wl0r.push_back(G(da0d, embc + p->l0_nmain, GA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, nullptr, nullptr, nullptr, list, list));
+        // its input gradient over the observed rows: da0_d [cnt, 2H] x W0_d [2H, E], added into the chunk's rows (cidx)
+        dl0.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d), dembc, nullptr, nullptr, nullptr, nullptr, nullptr, list));
+        if (p->l0_nmain < p->E)
+            dl0r.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, dembc + p->l0_nmain, nullptr, nullptr, nullptr, nullptr, nullptr, list));
         fl1.push_back(G(a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr, nullptr));
         fl2.push_back(G(a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr, nullptr));
         wl2.push_back(G(da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr, nullptr));
         dl2.push_back(G(da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d, GA(SHIVAE_P_DEC2_B, d)));
         wl1.push_back(G(da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr, nullptr));
-        // (cidx: the layer-0 backward is dense over the chunk, so a ragged launch scatters da0 back to chunk rows)
+        // (cidx: with SHIVAE_DEMB=dense the layer-0 backward is dense over the chunk, and a ragged launch scatters da0
+        // back to chunk rows)
         dl1.push_back(G(da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d,
                         p->grads + p->glob[SHIVAE_P_DEC0_B].off + (size_t)d * 2 * H, nullptr, nullptr, list));
         // heads (decoders.py:69-102)
@@ -438,6 +448,7 @@ static int build_tables(shivae_plan* p) {
     }
     SV_TRY(make_table(p, fl0, p->f_l0, all));
     SV_TRY(make_table(p, wl0, p->b_l0_w, all)); SV_TRY(make_table(p, wl0r, p->b_l0_wr, all));
+    SV_TRY(make_table(p, dl0, p->b_l0_d, all)); SV_TRY(make_table(p, dl0r, p->b_l0_dr, all));
     SV_TRY(make_table(p, fl1, p->f_l1, all)); SV_TRY(make_table(p, fl2, p->f_l2, all)); SV_TRY(make_table(p, fh0, p->f_h0, bc));
     SV_TRY(make_table(p, wl1, p->b_l1_w, all)); SV_TRY(make_table(p, dl1, p->b_l1_d, all));
     SV_TRY(make_table(p, wl2, p->b_l2_w, all)); SV_TRY(make_table(p, dl2, p->b_l2_d, all));
@@ -534,10 +545,11 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
 // rag_cnt: pinned host copy of the chunk's row counts while profiling (else null); see prof_ragged
 static const int* g_chunk_cnt_host = nullptr;
 static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epi, const GroupTable& t,
-                 hipStream_t s, int ragged = 0) {
+                 hipStream_t s, int ragged = 0, bool shared_c = false) {
     if (t.n == 0) return SHIVAE_OK;
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned, ragged};
-    if (epi == EPI_ATOMIC) {
+    // (shared_c: the groups add into the same C, so the adds stay atomic even with one workgroup per tile)
+    if (epi == EPI_ATOMIC && !shared_c) {
         d.splitk = splitk_for(M, N, K, t.n);
         if (d.splitk == 1 && use_addc()) d.epi = EPI_ADDC;
     }
@@ -724,6 +736,16 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
                 SV_CHECK_HIP(hipMemcpyAsync(blk, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
                 g_chunk_cnt_host = blk;
             }
+            if (p->demb_mode == 2 && p->obs_frac < 0.f) {
+                // which form of the layer-0 input gradient pays depends on how much is observed (see below): measured
+                // once per plan, on its first training chunk (the only host wait in a step, and only in that one)
+                std::vector<int> cnt(D);
+                SV_CHECK_HIP(hipMemcpyAsync(cnt.data(), rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
+                SV_CHECK_HIP(hipStreamSynchronize(s));
+                double tot = 0;
+                for (int c : cnt) tot += c;
+                p->obs_frac = (float)(tot / ((double)D * rc));
+            }
             SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, RAG_CNT | RAG_AIDX));
         } else {
             // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
@@ -776,25 +798,38 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
         SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
         SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
-        // (ragged: layer 0's backward below is dense over the chunk, so da0 goes back to chunk rows; the
-        // missing (row, attribute) blocks, which the row list skips, are cleared first)
-        if (rag) {
+        // Layer 0 backward, input gradient (the sum over attributes of decoders.py:127's shared input) in two forms.
+        // "compact": da0 stays compact like the activations and one grouped GEMM over the observed rows of every
+        // attribute ADDS its tiles into the chunk's rows: flops follow the observed fraction f, but every product is
+        // an fp32 atomic (measured 80 TFLOP/s of live flops).  "dense": da0 goes back to chunk rows (missing blocks
+        // cleared first) and one GEMM of K = D*2H sums over the attributes inside its K loop at 121 TFLOP/s,
+        // multiplying the zeros of the missing blocks.  Measured step times (B=256, T=100): f = 0.72 (cfg3) 159.4 ms
+        // compact / 157.1 dense; f = 0.11 (cfg5) 81.4 / 131.7.  auto: compact below f = 0.6.
+        const bool cd = rag && (p->demb_mode == 1 || (p->demb_mode == 2 && p->obs_frac >= 0.f && p->obs_frac < 0.6f));
+        if (rag && !cd) {
             if ((2 * H) % 4 == 0 && ldA0 % 4 == 0)
                 SV_TRY(launch_zero_missing_blocks(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, da0, ldA0, 2 * H, s));
             else
                 SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
         }
-        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s, rag ? RAG_CNT | RAG_CIDX : 0));
-        // layer 0: one weight-gradient GEMM for all attributes, one input-gradient GEMM summing over them
+        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s,
+                     rag ? (cd ? RAG_CNT : RAG_CNT | RAG_CIDX) : 0));
         if (rag) {
-            const int rl = RAG_CNT | RAG_AIDX | RAG_BIDX, nm = p->l0_nmain;
+            const int rl = cd ? RAG_CNT | RAG_BIDX : RAG_CNT | RAG_AIDX | RAG_BIDX, nm = p->l0_nmain;
             SV_TRY(gemmg(TN, 2 * H, nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_w, s, rl));
             if (nm < E) SV_TRY(gemmg(TN, 2 * H, E - nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_wr, s, rl));
         } else {
             SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                          EPI_ATOMIC, s));
         }
-        SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
+        if (cd) {
+            const int nm = p->l0_nmain;
+            SV_CHECK_HIP(hipMemsetAsync(dembc, 0, (size_t)rc * E4 * sizeof(float), s));
+            SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
+            if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_dr, s, RAG_CNT | RAG_CIDX, true));
+        } else {
+            SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
+        }
 
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
         // (SHIVAE_SYNC_CHUNKS=1: the host waits for each row chunk.  For runs under `rocprofv3 --pmc`, whose
@@ -1002,6 +1037,8 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         p->compact = f ? atoi(f) != 0 : 1;
         const char* hm = getenv("SHIVAE_HEADS");
         p->stream_heads = !(hm && strcmp(hm, "gemm") == 0);
+        const char* dm = getenv("SHIVAE_DEMB");
+        p->demb_mode = !dm ? 2 : strcmp(dm, "dense") == 0 ? 0 : strcmp(dm, "compact") == 0 ? 1 : 2;
     }
     build_workspace(p);
     *out = p;
@@ -1029,6 +1066,7 @@ int64_t shivae_plan_num_params(const shivae_plan* p) { return p ? p->n_params : 
 int shivae_plan_x_dim(const shivae_plan* p) { return p ? p->X : 0; }
 int shivae_plan_p_dim(const shivae_plan* p) { return p ? p->P : 0; }
 int shivae_plan_chunk_rows(const shivae_plan* p) { return p ? p->Rc : 0; }
+float shivae_plan_observed_fraction(const shivae_plan* p) { return p ? p->obs_frac : -1.f; }
 size_t shivae_plan_workspace_bytes(const shivae_plan* p) { return p ? p->ws_bytes : 0; }
 
 int shivae_plan_param_info(const shivae_plan* p, int id, int attr, int64_t* offset, int* rows, int* cols) {

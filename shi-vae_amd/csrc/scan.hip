@@ -130,7 +130,7 @@ template <int MAXS, int NTH, bool WLDS>
 __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NW = blockDim.x >> 6;
-    const int j = lane & 15, q = lane >> 4;
+    const int j = lane & 15;
     const int Hp = a.Hp, Zp = a.Zp, Kp = a.Kp, Ep = a.Ep, B = a.B;
     const int HT = Hp >> 4, ZT = Zp >> 4, KT = Kp >> 4;
     const int bj = blockIdx.x * 16 + j;
