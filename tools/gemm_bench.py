@@ -9,9 +9,9 @@ L = N.lib()
 def run(layout, M, Nn, K, lda, ldb, ldc, epi=0, splitk=1, iters=5, tag="", warm=1):
     rowsA = M if layout != 2 else K
     rowsB = Nn if layout == 0 else K
-    A = torch.randn(rowsA, lda, device="cuda")
+    A = torch.randn(rowsA if lda else 1, lda if lda else (K if layout != 2 else M), device="cuda")
     B = torch.randn(rowsB, ldb, device="cuda")
-    C = torch.zeros(M, ldc, device="cuda")
+    C = torch.zeros(M if ldc else 1, ldc if ldc else Nn, device="cuda")
     bias = torch.randn(Nn, device="cuda") if epi & 1 else None
     def go():
         N.check(L.shivae_gemm(layout, M, Nn, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C), ldc, N.ptr(bias) if epi & 1 else None, None, 0, epi, splitk, N.stream()))
@@ -68,10 +68,29 @@ def one(layout, M, Nn, K):
     run(layout, M, Nn, K, K if layout != 2 else M, K if layout == 0 else Nn, Nn, tag="one", iters=3, warm=0)
 
 
+def decoder():
+    """the decoder's K = 256 / 512 shapes at a chunk's worth of rows: NT (weights [N, K]) against NN (weights [K, N])"""
+    R = 1 << 20
+    for (n, k) in ((256, 256), (512, 256), (256, 512), (512, 528)):
+        run(0, R, n, k, k, k, n, tag="NT N=%d K=%d" % (n, k), iters=3)
+        run(1, R, n, k, k, n, n, tag="NN N=%d K=%d" % (n, k), iters=3)
+        run(0, R, n, k, k, k, n, epi=1 | 2, tag="NT bias+relu", iters=3)
+        run(1, R, n, k, k, n, n, epi=1 | 2, tag="NN bias+relu", iters=3)
+
+
+def nomem():
+    """where the time of a short-K NT GEMM goes: the same launch with the A rows and / or the C rows all at one address
+    (ld = 0: the operand stays in cache, the MFMA work and the instruction stream are unchanged)"""
+    R = 1 << 20
+    for (n, k) in ((256, 256), (512, 256), (256, 512)):
+        for (la, lc, tag) in ((k, n, "A, C in HBM"), (0, n, "A cached"), (k, 0, "C cached"), (0, 0, "A, C cached")):
+            run(0, R, n, k, la, k, lc, tag="NT N=%d K=%d %s" % (n, k, tag), iters=3)
+
+
 if __name__ == "__main__":
     import sys
     what = sys.argv[1] if len(sys.argv) > 1 else "main"
     if what == "one":
         one(*(int(v) for v in sys.argv[2:6]))
     else:
-        {"main": main, "long_k": long_k, "layer0": layer0}[what]()
+        {"main": main, "long_k": long_k, "layer0": layer0, "decoder": decoder, "nomem": nomem}[what]()
