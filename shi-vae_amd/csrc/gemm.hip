@@ -368,7 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     int bx, by, bz;
     if (!tile_coords(p, blockIdx.x, bx, by, bz)) return;  // padding of the last super-tiles (uniform per workgroup)
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     const int gidx = bz / p.splitk, ks = bz % p.splitk;
     const GemmGroup g = load_group(p, gidx);
     const int m0 = by * BM, n0 = bx * BN;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         ra.fetch(aidx, kbeg + 32, kend, tid);
         rb.fetch(bidx, kbeg + 32, kend, tid);
         __syncthreads();
-        if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
+        if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
         int cur = 0, k0 = kbeg;
         for (; k0 + 32 <= kend; k0 += 32) {  // whole K-tiles: no masking code in this loop
             if (k0 + 32 < kend) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         la.store(ldsA, tid);
         lb.store(ldsB, tid);
         __syncthreads();
-        if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
+        if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
         int cur = 0, k0 = kbeg;
         for (; k0 + 32 < kend; k0 += 32) {  // straight-line body (a branch per K-tile cost 5 % in the DMA loop)
             la.load(g.A, p.lda, m0, Mrows, k0 + 32, kend, tid, aidx);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
         }
     }
 
-    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
+    if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     const int epi = p.epi;
     constexpr int LDE = BN + 4;                              // padded row length of the staged tile
     constexpr int BANDS = WM * TM;                           // 32-row bands of the block tile
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
             if (p.stamps && tid == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are out
                 unsigned long long* o = p.stamps + 4ull * blockIdx.x;
-                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
             }
             return;
         }

@@ -87,10 +87,17 @@ def nomem():
             run(0, R, n, k, la, k, lc, tag="NT N=%d K=%d %s" % (n, k, tag), iters=3)
 
 
+def mscale():
+    """is the short-K shortfall per launch or per tile?  the K = 256 shape at 2^18 .. 2^22 rows"""
+    for sh in (18, 20, 22):
+        run(0, 1 << sh, 256, 256, 256, 256, 256, epi=3, tag="NT N=256 K=256 M=2^%d" % sh, iters=3, warm=2)
+        run(0, 1 << sh, 256, 512, 512, 512, 256, epi=3, tag="NT N=256 K=512 M=2^%d" % sh, iters=3, warm=2)
+
+
 if __name__ == "__main__":
     import sys
     what = sys.argv[1] if len(sys.argv) > 1 else "main"
     if what == "one":
         one(*(int(v) for v in sys.argv[2:6]))
     else:
-        {"main": main, "long_k": long_k, "layer0": layer0, "decoder": decoder, "nomem": nomem}[what]()
+        {"main": main, "long_k": long_k, "layer0": layer0, "decoder": decoder, "nomem": nomem, "mscale": mscale}[what]()

@@ -1,4 +1,4 @@
-"""Where a 128x128 GEMM workgroup spends its cycles (in-kernel s_memtime stamps): python tools/gemm_stamps.py M N K [epi]"""
+"""Where a 128x128 GEMM workgroup spends its time (in-kernel s_memrealtime stamps, 10 ns; s_memtime stops while a CU idles): python tools/gemm_stamps.py M N K [epi]"""
 import os, sys
 import numpy as np
 import torch
@@ -23,14 +23,14 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); go(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 N.check(L.shivae_debug_gemm_stamps(N.ptr(st)))
-go(); torch.cuda.synchronize()
+e0.record(); go(); e1.record(); torch.cuda.synchronize()
+ms_stamped = e0.elapsed_time(e1)
 N.check(L.shivae_debug_gemm_stamps(None))
 s = st.cpu().numpy().reshape(-1, 4)
 s = s[s[:, 3] > 0]
 pro, main, ep = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
 tot = s[:, 3] - s[:, 0]
-span = s[:, 3].max() - s[:, 0].min()
 print("M=%d N=%d K=%d epi=%d: %.3f ms, %.1f TF; %d workgroups stamped" % (M, Nn, K, epi, ms, 2.0 * M * Nn * K / ms / 1e9, len(s)))
 for nm, v in (("prologue", pro), ("main loop", main), ("epilogue", ep), ("total", tot)):
     print("  %-10s median %7.0f  p10 %7.0f  p90 %7.0f  (x100 MHz ticks)" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90)))
-print("  kernel span %d ticks; sum(total)/span = %.1f workgroups in flight on average" % (span, tot.sum() / span))
+print("  stamped launch %.3f ms; sum(total) / launch time = %.0f workgroups in flight on average (s_memrealtime: 100 MHz, per-XCD bases differ, so no global span)" % (ms_stamped, tot.sum() * 1e-5 / ms_stamped))
