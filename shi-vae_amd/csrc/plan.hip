@@ -736,7 +736,9 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
                 SV_CHECK_HIP(hipMemcpyAsync(blk, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
                 g_chunk_cnt_host = blk;
             }
-            if (p->demb_mode == 2 && p->obs_frac < 0.f) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);  // (no host wait inside a stream capture: the dense form is taken there)
+            if (p->demb_mode == 2 && p->obs_frac < 0.f && cap == hipStreamCaptureStatusNone) {
                 // which form of the layer-0 input gradient pays depends on how much is observed (see below): measured
                 // once per plan, on its first training chunk (the only host wait in a step, and only in that one)
                 std::vector<int> cnt(D);
