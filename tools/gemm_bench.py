@@ -94,10 +94,17 @@ def mscale():
         run(0, 1 << sh, 256, 512, 512, 512, 256, epi=3, tag="NT N=256 K=512 M=2^%d" % sh, iters=3, warm=2)
 
 
+def epiparts():
+    """vector (LDS-staged, 16-B stores) against scalar (registers -> 4-B stores, 128-B segments) epilogue: ldc = N + 1 takes the latter"""
+    for k in (256, 512):
+        run(0, 1 << 22, 256, k, k, k, 256, epi=3, tag="NT N=256 K=%d staged epilogue" % k, iters=3, warm=2)
+        run(0, 1 << 22, 256, k, k, k, 257, epi=3, tag="NT N=256 K=%d direct epilogue" % k, iters=3, warm=2)
+
+
 if __name__ == "__main__":
     import sys
     what = sys.argv[1] if len(sys.argv) > 1 else "main"
     if what == "one":
         one(*(int(v) for v in sys.argv[2:6]))
     else:
-        {"main": main, "long_k": long_k, "layer0": layer0, "decoder": decoder, "nomem": nomem, "mscale": mscale}[what]()
+        {"main": main, "long_k": long_k, "layer0": layer0, "decoder": decoder, "nomem": nomem, "mscale": mscale, "epiparts": epiparts}[what]()
