@@ -24,14 +24,23 @@ import sys
 import time
 
 T_PROC0 = time.perf_counter()
-
-import torch  # noqa: E402
+if os.environ.get("SHIVAE_BENCH_T0"):  # a rank started by launch_ranks(): the budget counts from the parent's start
+    T_PROC0 -= max(0.0, time.time() - float(os.environ["SHIVAE_BENCH_T0"]))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import shivae_amd  # noqa: E402
-from shivae_amd import _native as N  # noqa: E402
-from shivae_amd.synth import synth_batch  # noqa: E402
+# torch and the package are imported by main() AFTER the rank launcher below has had its say: the parent of an
+# N-rank run never touches the GPU
+torch = shivae_amd = N = synth_batch = None
+
+
+def _imports():
+    global torch, shivae_amd, N, synth_batch
+    import torch as _torch
+    import shivae_amd as _pkg
+    from shivae_amd import _native as _native
+    from shivae_amd.synth import synth_batch as _synth
+    torch, shivae_amd, N, synth_batch = _torch, _pkg, _native, _synth
 
 CONFIGS = {
     # name: (n_real, n_pos, n_bin, cat_classes, T, B, H, Z, K, miss)
@@ -146,6 +155,34 @@ def pmc_traffic(cfgname, B, T, kernel):
     return None, None
 
 
+def visible_gpus():
+    """Devices this process could use, WITHOUT initialising the GPU runtime (the launcher parent must stay clean)."""
+    import torch as _torch
+    return int(_torch.cuda.device_count())
+
+
+def launch_ranks(a, argv):
+    """`bench.py --gpus N` outside a torch.distributed.run launch: start N ranks (one per GPU, RCCL) as a CHILD
+    process -- this parent has not touched the GPU and never execs --, forward the child's output and exit code.
+    SHIVAE_BENCH_BACKEND=gloo lets the ranks share devices (rehearsals of the N>1 path on a box with fewer GPUs)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SHIVAE_BENCH_BACKEND", "nccl")
+    ndev = visible_gpus()
+    if backend == "nccl" and a.gpus > ndev:
+        print("bench.py: %d ranks requested, %d device%s visible (one rank per GPU over RCCL; set "
+              "SHIVAE_BENCH_BACKEND=gloo to rehearse with shared devices)" % (a.gpus, ndev, "" if ndev == 1 else "s"),
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, SHIVAE_BENCH_T0=repr(time.time() - (time.perf_counter() - T_PROC0)))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,9 +200,19 @@ def main():
                     help="wall-clock seconds for the whole process; counts are clamped to fit")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:  # never label an N-rank request with another rank count
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or plain `python bench.py "
+                  "--gpus %d`, which starts the ranks itself)" % (a.gpus, world, a.gpus, a.gpus), file=sys.stderr, flush=True)
+        sys.exit(2)
+    _imports()
     # (one rank per GPU; SHIVAE_BENCH_BACKEND=gloo lets several ranks rehearse the N>1 path on a box with fewer GPUs)
     backend = os.environ.get("SHIVAE_BENCH_BACKEND", "nccl")
     ndev = max(torch.cuda.device_count(), 1)

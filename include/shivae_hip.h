@@ -114,6 +114,10 @@ enum {
 const char* shivae_last_error(void);
 /* build id string, e.g. "shivae_hip gfx950 <date>" */
 const char* shivae_version(void);
+/* Per-device set-up for the CURRENT device (today: the device address of the scratch array of shivae_sqnorm_noalloc).
+ * shivae_plan_bind calls it too; call it yourself, outside any stream capture, on a device that never binds a plan.
+ * No counterpart in the reference. */
+int shivae_init(void);
 
 /* ---- plan: model description, parameter layout, workspace ---------------------------------- */
 /* replaces ShiVAE.__init__ bookkeeping (shivae.py:25-70, utils.py:229-241,291-315) */
@@ -134,6 +138,11 @@ int shivae_plan_chunk_rows(const shivae_plan* plan);
  * on, which picks the form of the decoder's layer-0 input gradient (SHIVAE_DEMB); < 0 before the
  * first training step or when SHIVAE_DEMB forces a form.  No counterpart in the reference. */
 float shivae_plan_observed_fraction(const shivae_plan* plan);
+/* Set that fraction instead of having the first training chunk measured (which costs one host wait inside that step
+ * and cannot happen under stream capture): f in [0,1] picks the form (compact below 0.6), f < 0 asks for a new
+ * measurement.  shivae_plan_bind resets it to "not measured".  With the compact form the layer-0 input gradient is
+ * summed with fp32 atomics shared by the attributes: its summation order, hence its last bits, vary run to run. */
+int shivae_plan_set_observed_fraction(shivae_plan* plan, float f);
 
 size_t shivae_plan_workspace_bytes(const shivae_plan* plan);
 /* attach caller-owned device memory: workspace (>= workspace_bytes, 256-B aligned; it is zeroed
@@ -251,7 +260,10 @@ int shivae_sqnorm(const float* buf_dev, int64_t n, float* scratch_dev, float* ou
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The block partials live in
  * a 4 KiB file-scope device array that every GPU the library runs on holds until the process ends; the entry point
  * calls no hipMalloc / hipFree.  n is limited to SHIVAE_SQNORM_NOALLOC_MAX elements (larger n is rejected).  All
- * calls on one GPU share that array: calls that overlap on one GPU (two streams) race -- serialise them. */
+ * calls on one GPU share that array: calls that overlap on one GPU (two streams) race -- serialise them.
+ * The device of `stream` must be the current device (checked).  The array's device address is resolved by
+ * shivae_init / shivae_plan_bind; a first use on a device that saw neither resolves it on the spot, which is refused
+ * with an error when that first use is inside a stream capture. */
 #define SHIVAE_SQNORM_NOALLOC_MAX ((int64_t)1 << 32)
 int shivae_sqnorm_noalloc(const float* buf_dev, int64_t n, float* out_dev, shivae_stream stream);
 /* torch.nn.utils.clip_grad_norm_(params, clip) followed by torch.optim.Adam.step()

@@ -27,7 +27,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 16, 32
 
 # every symbol include/shivae_hip.h declares
-SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_plan_create", "shivae_plan_destroy",
+SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_init", "shivae_plan_set_observed_fraction", "shivae_plan_create", "shivae_plan_destroy",
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
            "shivae_plan_chunk_rows", "shivae_plan_observed_fraction", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
@@ -75,6 +75,8 @@ def lib():
         getattr(L, f).argtypes = [vp]
     L.shivae_plan_observed_fraction.argtypes = [vp]
     L.shivae_plan_observed_fraction.restype = cf
+    L.shivae_plan_set_observed_fraction.argtypes = [vp, cf]
+    L.shivae_init.argtypes = []
     L.shivae_plan_workspace_bytes.argtypes = [vp]
     L.shivae_plan_workspace_bytes.restype = C.c_size_t
     L.shivae_plan_bind.argtypes = [vp, vp, C.c_size_t, vp, vp]

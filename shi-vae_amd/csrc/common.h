@@ -215,6 +215,7 @@ int launch_transpose(const float* in, float* out, int R, int C, int batch, size_
                      hipStream_t stream);
 int launch_sqnorm(const float* buf, int64_t n, float* scratch, float* out, hipStream_t stream);
 int launch_sqnorm_noalloc(const float* buf, int64_t n, float* out, hipStream_t stream);
+int init_sqnorm_noalloc();
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sqnorm, float clip,
                      float lr, float b1, float b2, float eps, int step, hipStream_t stream);
 

@@ -147,15 +147,37 @@ static __device__ __align__(256) float scratch[1024];
 static constexpr int kMaxDevices = 64;
 static float* g_scratch_ptr[kMaxDevices] = {nullptr};
 
-int launch_sqnorm_noalloc(const float* buf, int64_t n, float* out, hipStream_t stream) {
+// Set-up for the CURRENT device: resolve its copy of the array once.  Called by shivae_init and shivae_plan_bind
+// (both outside any stream capture); the entry point itself only falls back to it on a device neither has seen.
+int init_sqnorm_noalloc() {
     int dev = -1;
     SV_CHECK_HIP(hipGetDevice(&dev));
     SV_REQUIRE(dev >= 0 && dev < kMaxDevices, "sqnorm_noalloc: device ordinal %d out of range", dev);
-    if (!g_scratch_ptr[dev]) {  // first call on this device (with it current): resolve this device's copy once
+    if (!g_scratch_ptr[dev]) {
         void* ptr = nullptr;
         SV_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         SV_REQUIRE(ptr != nullptr, "sqnorm_noalloc: no device address for the scratch array");
         g_scratch_ptr[dev] = static_cast<float*>(ptr);
+    }
+    return SHIVAE_OK;
+}
+
+int launch_sqnorm_noalloc(const float* buf, int64_t n, float* out, hipStream_t stream) {
+    int dev = -1;
+    SV_CHECK_HIP(hipGetDevice(&dev));
+    SV_REQUIRE(dev >= 0 && dev < kMaxDevices, "sqnorm_noalloc: device ordinal %d out of range", dev);
+    if (stream) {  // the array is per device: the stream must belong to the current one
+        int sdev = dev;
+        if (hipStreamGetDevice(stream, &sdev) == hipSuccess)
+            SV_REQUIRE(sdev == dev, "sqnorm_noalloc: stream is on device %d, current device is %d", sdev, dev);
+    }
+    if (!g_scratch_ptr[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        SV_REQUIRE(cap == hipStreamCaptureStatusNone,
+                   "sqnorm_noalloc: first use on device %d is inside a stream capture; call shivae_init() (or bind a "
+                   "plan) on this device beforehand", dev);
+        SV_TRY(init_sqnorm_noalloc());
     }
     // all `parts` partials are overwritten before the final kernel reads them: nothing has to start at zero
     return launch_sqnorm(buf, n, g_scratch_ptr[dev], out, stream);

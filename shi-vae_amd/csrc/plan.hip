@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1069,6 +1070,12 @@ int shivae_plan_x_dim(const shivae_plan* p) { return p ? p->X : 0; }
 int shivae_plan_p_dim(const shivae_plan* p) { return p ? p->P : 0; }
 int shivae_plan_chunk_rows(const shivae_plan* p) { return p ? p->Rc : 0; }
 float shivae_plan_observed_fraction(const shivae_plan* p) { return p ? p->obs_frac : -1.f; }
+int shivae_plan_set_observed_fraction(shivae_plan* p, float f) {
+    SV_REQUIRE(p, "set_observed_fraction: null plan");
+    SV_REQUIRE(f <= 1.f, "set_observed_fraction: %g is not a fraction", (double)f);
+    p->obs_frac = f < 0.f ? -1.f : f;
+    return SHIVAE_OK;
+}
 size_t shivae_plan_workspace_bytes(const shivae_plan* p) { return p ? p->ws_bytes : 0; }
 
 int shivae_plan_param_info(const shivae_plan* p, int id, int attr, int64_t* offset, int* rows, int* cols) {
@@ -1093,6 +1100,7 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
     SV_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) == 0,
                "plan_bind: parameter/gradient buffers must be 16-B aligned");
     release_bound(p);
+    p->obs_frac = -1.f;  // (measured again on the first training chunk of the new binding, unless the caller sets it)
     p->f_out.clear(); p->b_out_w.clear(); p->b_out_d.clear(); p->c_out.clear(); p->h_out.clear();
     p->ws = static_cast<char*>(ws);
     p->params = params;
@@ -1109,6 +1117,7 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
                                    hipHostMallocDefault));
         p->cnt_next = 0;
     }
+    SV_TRY(init_sqnorm_noalloc());  // (per-device set-up happens here, outside any stream capture)
     SV_TRY(upload(p, p->attrs, &p->attrs_dev));
     std::vector<PackJob> wj, bj;
     build_pack_plan(p, wj, bj, true);
@@ -1395,6 +1404,8 @@ int shivae_sqnorm(const float* buf, int64_t n, float* scratch, float* out, shiva
     return launch_sqnorm(buf, n, scratch, out, static_cast<hipStream_t>(stream));
 }
 
+int shivae_init(void) { return init_sqnorm_noalloc(); }
+
 int shivae_sqnorm_noalloc(const float* buf, int64_t n, float* out, shivae_stream stream) {
     SV_REQUIRE(buf && out && n >= 0, "sqnorm_noalloc: bad argument");
     SV_REQUIRE(n <= SHIVAE_SQNORM_NOALLOC_MAX, "sqnorm_noalloc: %lld elements exceed the supported maximum of %lld",
@@ -1417,9 +1428,8 @@ struct RcclApi {
 };
 static int rccl_api(const RcclApi** out) {
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
@@ -1433,7 +1443,7 @@ static int rccl_api(const RcclApi** out) {
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
         }
-    }
+    });
     if (!api.handle || !api.AllReduce || !api.GroupStart || !api.GroupEnd || !api.GetUniqueId || !api.CommInitRank ||
         !api.CommDestroy || !api.GetErrorString) {
         set_error("RCCL not available: %s", api.handle ? "librccl lacks a required symbol" : dlerror());
@@ -1489,9 +1499,17 @@ int shivae_allreduce_grads(float* grads, int64_t n, void* comm, int64_t bucket_f
     // one group of in-place sums, bucket by bucket: ring collectives over xGMI are bound per link, and buckets of
     // ~100 MB keep every link streaming while staying small enough to pipeline
     SV_CHECK_RCCL(api, api->GroupStart());
-    for (int64_t a = 0; a < n; a += b)
-        SV_CHECK_RCCL(api, api->AllReduce(grads + a, grads + a, (size_t)std::min<int64_t>(b, n - a), ncclFloat, ncclSum,
-                                          static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)));
+    for (int64_t a = 0; a < n; a += b) {
+        const ncclResult_t r = api->AllReduce(grads + a, grads + a, (size_t)std::min<int64_t>(b, n - a), ncclFloat, ncclSum,
+                                              static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream));
+        if (r != ncclSuccess) {
+            // close the group before reporting: an open group would swallow every later collective of this thread
+            // (torch's included)
+            (void)api->GroupEnd();
+            set_error("allreduce_grads: ncclAllReduce of bucket at %lld -> %s", (long long)a, api->GetErrorString(r));
+            return SHIVAE_ERR_HIP;
+        }
+    }
     SV_CHECK_RCCL(api, api->GroupEnd());
     return SHIVAE_OK;
 }

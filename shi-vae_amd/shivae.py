@@ -220,8 +220,8 @@ class ShiVAE(nn.Module):
 
     def _publish_grads(self, go=None):
         fresh = self._slices[0][0].grad is None
-        if go is not None and fresh and self._pending_reduce:
-            for w in self._pending_reduce[0][1]:  # (the scaling below must not race with buckets in flight)
+        if self._pending_reduce:
+            for w in self._pending_reduce[0][1]:  # (nothing below may race with buckets in flight, fresh or not)
                 w.wait()
         if go is not None and fresh:
             self._gflat.mul_(go.reshape(()))
@@ -342,6 +342,14 @@ class ShiVAE(nn.Module):
         assert X == self.x_dim, "x has %d columns, types_list implies %d" % (X, self.x_dim)
         u, eps = self._draw_noise(T, B)
         inv_batch = 1.0 / B if inv_batch is None else float(inv_batch)
+        if grad and self._pending_reduce:
+            # A second training forward before allreduce_grads() (gradient accumulation): the decoder buckets of the
+            # first forward are still in flight and already hold rank-summed values.  Accumulating on top of them and
+            # reducing again would scale the first forward's part by the world size, so this is refused outright.
+            raise RuntimeError("ShiVAE: a training forward was run with overlap_allreduce on while the gradient "
+                               "buckets of the previous forward are still pending; call allreduce_grads() after every "
+                               "backward, or set model.overlap_allreduce = False to accumulate gradients over "
+                               "several forwards and reduce once")
         losses = torch.zeros(16, dtype=torch.float32, device=dev)
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
         bm = self.micro_batches(T, B)[0]
@@ -357,7 +365,7 @@ class ShiVAE(nn.Module):
             else:
                 xs, ms = x[:, b0:b1].contiguous(), mask[:, b0:b1].contiguous()
                 us, es = u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous()
-            if grad and b1 == B and self.overlap_allreduce and self._dp_backend() == "nccl":
+            if grad and b1 == B and self.overlap_allreduce and self._dp_backend() == "nccl" and not self._pending_reduce:
                 # last micro-batch of a data-parallel step, phase by phase (== shivae_elbo_step): the decoder's
                 # gradients are final once its last row chunk is done
                 st, m8 = N.stream(), ms.view(torch.uint8)

@@ -149,9 +149,27 @@ class Trainer:
         epoch_loss, _ = self.init_loss_dict()
         beta = self.annealing_weight.update_beta(epoch)
         self.model.train()
-        self.model.overlap_allreduce = True  # (this loop calls allreduce_grads() after every backward)
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 and hasattr(train_loader, "__len__"):
+            # every rank must run the same number of steps: each step holds collectives
+            nb = torch.tensor([len(train_loader), -len(train_loader)], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                nb = nb.to(self.model.flat_params.device)
+            dist.all_reduce(nb, op=dist.ReduceOp.MIN)
+            lo, hi = int(nb[0]), -int(nb[1])
+            if lo != hi:
+                raise RuntimeError("data-parallel train_epoch: the ranks' loaders have between %d and %d batches; "
+                                   "shard the dataset so that every rank gets the same number" % (lo, hi))
+        prev_overlap = self.model.overlap_allreduce
+        self.model.overlap_allreduce = True  # (this loop calls allreduce_grads() after every backward)
+        try:
+            return self._train_batches(train_loader, epoch, epoch_loss, beta, world)
+        finally:
+            self.model.overlap_allreduce = prev_overlap
+
+    def _train_batches(self, train_loader, epoch, epoch_loss, beta, world):
+        import torch.distributed as dist
         for data, mask, _attrs in train_loader:
             data, mask = self.preprocess_batch(data, mask)
             data = utils.zero_fill(data, mask)
@@ -161,7 +179,11 @@ class Trainer:
                 # data parallel over the batch: every rank scales by 1/B_global (ragged last batches: the summed
                 # count), so the all-reduced SUM of the flat gradients is the global-batch gradient that
                 # clip_grad_norm_ sees in the reference (trainers.py:222)
-                cnt = torch.tensor([float(data.shape[1])], device=data.device)
+                # (the count is known on the host: a host tensor for gloo -- a device tensor handed to gloo while
+                # kernels are in flight is the pattern that hung two ranks on one GPU)
+                cnt = torch.tensor([float(data.shape[1])], dtype=torch.float64)
+                if dist.get_backend() == "nccl":
+                    cnt = cnt.to(data.device)
                 dist.all_reduce(cnt)
                 inv_batch = 1.0 / float(cnt.item())
             loss_dict = self.model(data, mask=mask, beta=beta, temp=self.temp, inv_batch=inv_batch)
@@ -172,6 +194,8 @@ class Trainer:
                 # the 9 logged scalars are per-rank shares of the global means: sum them; a NaN on any rank becomes
                 # a NaN on all of them, so every rank takes the same branch below (none is left inside a collective)
                 vals = torch.stack([loss_dict[k].detach() for k in self.loss_list])
+                if dist.get_backend() != "nccl":
+                    vals = vals.cpu()  # (blocking copy = the wait for the step; see above)
                 dist.all_reduce(vals)
                 loss_dict = {k: vals[i] for i, k in enumerate(self.loss_list)}
                 n_elbo = loss_dict['n_elbo']

@@ -33,3 +33,30 @@ def golden_dec_params(g, types_list, prefix="dec"):
         else:
             out.append(g["%s/%d/theta" % (prefix, i)])
     return out
+
+
+# ---- the two gradient criteria of the step tests (stated fp32 tolerances) ----
+GRAD_RTOL = 5e-4     # max|got - ref| relative to the largest |ref| entry of the tensor
+GRAD_L2_RTOL = 1e-3  # ||got - ref||_2 relative to ||ref||_2 of the tensor
+
+
+def grad_errors(got, ref):
+    """(max-norm error, L2 error) of one gradient tensor against its reference.  The max-norm figure alone lets rows
+    of small magnitude (the bias of an attribute observed 10 % of the time next to one observed always) be wrong by
+    100 %; the L2 figure is per tensor -- per attribute for the decoder's parameters -- and has no such blind spot.
+    Floors: tensors whose reference gradient is exactly zero (never-observed attributes) must come out ~zero."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    d = got - ref
+    e_max = np.abs(d).max() / max(np.abs(ref).max(), 1e-3)
+    e_l2 = np.sqrt((d * d).sum()) / max(np.sqrt((ref * ref).sum()), 1e-3 * np.sqrt(ref.size))
+    return float(e_max), float(e_l2)
+
+
+def bad_grads(named_grads, G, rtol=GRAD_RTOL, l2_rtol=GRAD_L2_RTOL):
+    """[(name, max-norm error, L2 error)] of the tensors that miss either criterion, worst first."""
+    bad = []
+    for k, g in named_grads:
+        e_max, e_l2 = grad_errors(g, G[k])
+        if not (e_max < rtol and e_l2 < l2_rtol):
+            bad.append((k, e_max, e_l2))
+    return sorted(bad, key=lambda t: -max(t[1] / rtol, t[2] / l2_rtol))

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import _golden
 import shivae_amd
 from oracle import shivae_oracle as so
 from shivae_amd import _native as N
@@ -94,12 +95,8 @@ def test_step_at_baseline_attribute_mix(name):
     for k in shivae_amd.LOSS_KEYS:
         np.testing.assert_allclose(float(loss[k]), c["losses"][k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
     loss["n_elbo"].backward()
-    bad = []
-    for k, p in m.named_parameters():
-        err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
-        if not err < GRAD_RTOL:
-            bad.append((k, float(err)))
-    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+    bad = _golden.bad_grads([(k, p.grad.cpu().numpy()) for k, p in m.named_parameters()], G)
+    assert not bad, bad[:8]
     # forward tensors of the dense (imputation) form of the same decoder
     m.eval()
     m.set_noise(u, eps)

@@ -241,6 +241,9 @@ SCAN_CASES = {
     "h16": (1, 1, 1, [3], 9, 21, 16, 4, 3),
     "h80_multiwave": (2, 1, 1, [5], 6, 18, 80, 24, 6),
     "k20_two_ktiles": (2, 1, 1, [3], 5, 17, 32, 6, 20),
+    # scan_fwd_kernel<2,512> / scan_bwd_kernel<2,512>: the instantiation of the cfg3 benchmark (8 waves, two hidden
+    # tiles per wave), T = 64 steady-state steps of its weight / record pipelines, a full and a ragged sequence tile
+    "h256_T64": (1, 1, 1, [4], 64, 20, 256, 64, 16),
 }
 
 
@@ -288,10 +291,10 @@ def test_scan_fwd_and_bwd_records_match_oracle(name):
         assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), (k, np.abs(got - ref).max(), np.abs(ref).max())
     # ... and the parameter gradients this phase owns (the recurrent cell, the encoder, phi_x)
     m._publish_grads(None)
-    for k, p in m.named_parameters():
-        if k.startswith(("encoder.", "phi_z.", "rnn.")):
-            err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
-            assert err < 5e-4, (k, err)
+    import _golden
+    bad = _golden.bad_grads([(k, p.grad.cpu().numpy()) for k, p in m.named_parameters()
+                             if k.startswith(("encoder.", "phi_z.", "rnn."))], G)
+    assert not bad, bad[:8]
 
 
 def test_phases_compose_to_the_step():

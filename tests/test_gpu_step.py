@@ -15,7 +15,12 @@ pytestmark = pytest.mark.gpu
 # stated fp32 tolerances (north_star "within a stated fp32 tolerance")
 FWD_RTOL, FWD_ATOL = 1e-4, 2e-5
 LOSS_RTOL = 2e-5
-GRAD_RTOL = 5e-4  # relative to the largest |grad| entry of each tensor
+GRAD_RTOL = _golden.GRAD_RTOL  # relative to the largest |grad| entry of each tensor; next to it, every step test holds
+#                               ||got - ref||_2 / ||ref||_2 < _golden.GRAD_L2_RTOL per tensor (_golden.bad_grads)
+
+
+def _grads(m):
+    return [(k, p.grad.cpu().numpy()) for k, p in m.named_parameters()]
 
 
 @pytest.fixture(params=["f32_mfma", "split_bf16"], autouse=True)
@@ -64,11 +69,9 @@ def test_losses_and_gradients_match_reference(name):
     for k in shivae_amd.LOSS_KEYS:
         np.testing.assert_allclose(float(loss[k]), g["loss/" + k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
     loss["n_elbo"].backward()
-    for k, p in m.named_parameters():
-        ref = g["grad/" + k]
-        assert p.grad is not None, k
-        err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
-        assert err < GRAD_RTOL, (k, err)
+    assert all(p.grad is not None for p in m.parameters())
+    bad = _golden.bad_grads(_grads(m), {k: g["grad/" + k] for k, _ in m.named_parameters()})
+    assert not bad, bad[:8]
     # per-sequence sums over t of the six terms (base_missvae.py:284,318,343)
     ps = m._last["persum"].cpu().numpy()
     assert ps.shape == (cfg["B"], 6)
@@ -156,6 +159,9 @@ CASES = {
     "only_cat": (shivae_amd.utils.make_types_list(0, 0, 0, [2, 3, 9]), 7, 9, 16, 4, 3, True, 0.2, 0),
     "all_missing": (shivae_amd.utils.make_types_list(1, 1, 1, [3]), 6, 8, 16, 4, 3, True, 1.0, 0),
     "h256_16waves": (shivae_amd.utils.make_types_list(1, 1, 1, [3]), 4, 40, 256, 64, 16, True, 0.3, 0),
+    # the scan instantiation the cfg3 benchmark runs (H=256, Z=64, K=16: 8 waves, two hidden tiles per wave) at a
+    # sequence length where its software pipelines are in steady state: one full and one ragged 16-sequence tile
+    "h256_T64": (shivae_amd.utils.make_types_list(1, 1, 1, [4]), 64, 20, 256, 64, 16, True, 0.3, 0),
 }
 
 
@@ -183,9 +189,8 @@ def test_step_matches_oracle_on_seeded_inputs(name):
     for k in shivae_amd.LOSS_KEYS:
         np.testing.assert_allclose(float(loss[k]), c["losses"][k], rtol=LOSS_RTOL, atol=1e-5, err_msg=k)
     loss["n_elbo"].backward()
-    for k, p in m.named_parameters():
-        err = np.abs(p.grad.cpu().numpy() - G[k]).max() / max(np.abs(G[k]).max(), 1e-3)
-        assert err < GRAD_RTOL, (k, err)
+    bad = _golden.bad_grads(_grads(m), G)
+    assert not bad, bad[:8]
 
 
 def test_mask_aware_decoder_matches_dense(monkeypatch):

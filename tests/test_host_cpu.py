@@ -107,3 +107,20 @@ def test_synthetic_batch_shards_by_sequence_block():
         assert torch.equal(xs, x[:, 16 * r:16 * (r + 1)]) and torch.equal(ms, m[:, 16 * r:16 * (r + 1)])
     assert 0.2 < float(m.float().mean()) < 0.4
     assert float(x[m].abs().max()) == 0.0  # zero-filled where missing
+
+
+def test_bench_refuses_rank_counts_it_cannot_run():
+    """bench.py --gpus N: more ranks than devices over RCCL, or a launch whose WORLD_SIZE differs from --gpus, exit
+    non-zero without printing a result line (no GPU is touched before that decision)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SHIVAE_BENCH_BACKEND")}
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "%d ranks requested, %d device" % (n, n - 2) in r.stderr, r.stderr[-500:]
+    assert "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr, r.stderr[-500:]

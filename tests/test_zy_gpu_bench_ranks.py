@@ -19,12 +19,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _clean_env(**kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SHIVAE_BENCH_T0")}
+    env.update(kw)
+    return env
+
+
 def test_two_ranks_on_one_gpu():
-    env = dict(os.environ, SHIVAE_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config",
+    """`python bench.py --gpus 2` itself starts the two ranks (bench.py launch_ranks)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config",
            "cfg1", "--batch", "16", "--T", "20", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(SHIVAE_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints
@@ -33,6 +39,24 @@ def test_two_ranks_on_one_gpu():
     assert j["config"]["global_batch"] == 16 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["n_elbo"] == j["n_elbo"]  # finite
     assert j["roofline"] is not None and "cpu_baseline" not in j
+
+
+def test_more_ranks_than_devices_is_refused():
+    """RCCL needs one GPU per rank: `bench.py --gpus 8` on a box with fewer devices must fail, not print a line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "cfg1"], cwd=ROOT,
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "%d ranks requested, %d device" % (n, n - 1) in r.stderr, r.stderr[-1000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rank_count_mismatch_is_refused():
+    """A launch whose WORLD_SIZE differs from --gpus must not label its line with either number."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg1"], cwd=ROOT,
+                       env=_clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr, r.stderr[-1000:]
 
 
 _DP_SCRIPT = r'''
@@ -87,13 +111,24 @@ args = types.SimpleNamespace(l_rate=5e-3, n_epochs=1, kl_annealing_epochs=0, cli
 tr = shivae_amd.Trainer(m, shivae_amd.FusedClipAdam(m, lr=5e-3), args)
 m.set_noise(u[:, sl], eps[:, sl])
 shard = (np.ascontiguousarray(x[:, sl].transpose(1, 0, 2)), np.ascontiguousarray(mask[:, sl].transpose(1, 0, 2)), None)
+assert m.overlap_allreduce is False
 logged = tr.train_epoch([shard], 1)
+assert m.overlap_allreduce is False          # (train_epoch restores the caller's setting)
 et = float((m.flat_params - p_ref).abs().max())
 assert et < 1e-4, ("Trainer.train_epoch under data parallel", et)
 single = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
 single.flat_params.copy_(p0); single.eval(); single.set_noise(u, eps)
 ref_loss = float(single(xt, mt, beta=1.0, temp=3)["n_elbo"])
 assert abs(logged["n_elbo"] - ref_loss) < 1e-4 * abs(ref_loss), (logged["n_elbo"], ref_loss)
+# two batches per epoch: the second iteration's collectives come while the first one's kernels may still be in flight
+tr.train_epoch([shard, shard], 2)
+assert bool(torch.isfinite(m.flat_params).all())
+# ranks whose loaders disagree on the number of batches must fail loudly instead of hanging in a collective
+try:
+    tr.train_epoch([shard] * (1 + r), 3)
+    raise SystemExit("mismatched loaders were not refused")
+except RuntimeError as e:
+    assert "same number" in str(e)
 print("rank %%d ok: grad %%.2e params %%.2e trainer %%.2e" %% (r, eg, ep, et), flush=True)
 dist.destroy_process_group()
 '''
@@ -148,6 +183,31 @@ for overlap, micro in ((False, 0), (True, 0), (True, 16)):
 for l, g in res[1:]:
     assert abs(l - res[0][0]) < 1e-5 * abs(res[0][0]), (l, res[0][0])
     assert float((g - res[0][1]).abs().max()) < 1e-4 * float(res[0][1].abs().max())
+
+# gradient accumulation: a second training forward while the first one's buckets are pending must be refused (it
+# would re-reduce already rank-summed values); with the overlap off, two forwards accumulate and reduce once
+torch.manual_seed(0)
+m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+m.train(); m.overlap_allreduce = True; m.bucket_floats = 1000
+m.zero_grad(); m.set_noise(u, eps)
+m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.9, temp=2.0)
+assert m._pending_reduce
+try:
+    m.set_noise(u, eps)
+    m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.9, temp=2.0)
+    raise SystemExit("second forward with pending buckets was not refused")
+except RuntimeError as e:
+    assert "allreduce_grads" in str(e)
+m.allreduce_grads()
+assert not m._pending_reduce
+m.overlap_allreduce = False
+m.zero_grad()
+for _ in range(2):
+    m.set_noise(u, eps)
+    m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.9, temp=2.0)["n_elbo"].backward()
+m.allreduce_grads()
+torch.cuda.synchronize()
+assert float((m.flat_grads - 2 * res[0][1]).abs().max()) < 2e-4 * float(res[0][1].abs().max())
 
 # the C-ABI all-reduce on a communicator of its own (one rank: the sum is the buffer itself)
 L = N.lib()
