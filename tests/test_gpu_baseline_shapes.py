@@ -36,33 +36,7 @@ MIXES = {
 }
 
 
-def _dekink_decoder(P, tl, emb, delta=2e-5, bump=1e-3):
-    """ReLU gates are decided in fp32 on the GPU and in fp64 by the oracle.  These shapes have ~2e7 decoder
-    ReLU inputs, so a dozen of them sit within fp32 rounding of zero, the two sides gate them differently, and with
-    only T*B = 72 rows one flipped gate moves a layer's gradient by per cent (seen: 0.155 of max|grad| on one
-    dec.0.weight, identical in the dense and the mask-aware form).  That is the test's conditioning, not the
-    kernels': nudge the bias of every decoder unit that has an input within `delta` of zero, layer by layer."""
-    a_in = emb.reshape(-1, emb.shape[-1]).astype(np.float64)
-    moved = 0
-    for t in tl:
-        pre = "dec.decoder_dict.%s." % t["name"]
-        layers = ["dec.0", "dec.2", "dec.4"] + {"bin": ["dec_p.0"], "cat": ["dec_p_cat.0"]}.get(t["type"], [])
-        a = a_in
-        for L in layers:
-            W = P[pre + L + ".weight"].astype(np.float64)
-            b = P[pre + L + ".bias"].astype(np.float32)
-            for _ in range(16):
-                z = a @ W.T + b.astype(np.float64)
-                near = (np.abs(z) < delta).any(axis=0)
-                if not near.any():
-                    break
-                b[near] += np.float32(bump)
-                moved += int(near.sum())
-            else:
-                raise AssertionError("could not move %s%s off its kinks" % (pre, L))
-            P[pre + L + ".bias"] = b
-            a = np.maximum(z, 0)
-    return moved
+from _golden import dekink_decoder as _dekink_decoder  # noqa: E402
 
 
 @pytest.mark.parametrize("name", list(MIXES))

@@ -179,6 +179,11 @@ def test_step_matches_oracle_on_seeded_inputs(name):
     beta, temp = 0.8, 1.5
     om = so.OracleShiVAE(P, tl, H, Z, K, learn_std)
     c = om.forward(x, mask, u, eps, beta, temp)
+    # (H = 256 over 1 280 rows is ~5e6 decoder ReLU inputs: move the units that sit within fp32 rounding of a kink,
+    # where the fp32 GPU and the fp64 oracle gate differently -- _golden.dekink_decoder)
+    if H >= 256 and T * B > 1000 and _golden.dekink_decoder(P, tl, c["emb"]):
+        om = so.OracleShiVAE(P, tl, H, Z, K, learn_std)
+        c = om.forward(x, mask, u, eps, beta, temp)
     G = om.backward()
     m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=learn_std)
     m.chunk_rows = chunk
