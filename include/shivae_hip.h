@@ -248,9 +248,29 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
 /* Arithmetic of the 128x128-tile GEMMs (the decoder: 99 % of the step's flops).  0 (default): fp32-input MFMA
  * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  1: every fp32 operand is split EXACTLY into three bf16 terms and
  * a product is accumulated in fp32 from the six bf16 MFMA products that matter (v_mfma_f32_32x32x16_bf16; the
- * dropped cross terms are <= 2^-23 of the product): same inputs, same outputs, fp32-level error, 2-3x the rate.
+ * dropped cross terms are <= 2^-26 of the product): same inputs, same outputs, fp32-level error, 2-3x the rate.
  * Also selectable with SHIVAE_GEMM_SPLIT=1.  No counterpart in the reference. */
 int shivae_set_gemm_split(int on);
+/* Split-mode arithmetic in full (tests/test_gpu_split_mode.py holds it against the fp32-input MFMA on adversarial
+ * operands, both against fp64): x = hi + mid + lo exactly, each term the NEAREST bf16 of what is left; a*b is
+ * accumulated as ah*bh in one fp32 accumulator and (ah*bm + am*bh + am*bm + ah*bl + al*bh) in a second one, added at
+ * the end; the dropped terms are <= 2^-26 |a b|.  Measured error <= the fp32-input MFMA's on the same operands
+ * (K up to 131 072, magnitudes spread over 2^+-40 in one row, cancellation of 12 bits, operands down to 2^-100).
+ * Outside the contract: operands that are fp32 DENORMALS (|x| < 2^-126) -- the bf16 matrix cores flush denormal
+ * inputs, so they count as zero or as their leading term only; and +-inf operands, which give NaN (inf - hi(inf))
+ * where the fp32-input MFMA gives +-inf or NaN.  NaN propagates as NaN in both modes; every output that touches no
+ * non-finite operand is unaffected.
+ *
+ * The decoder's weight operands are split ONCE per step into a bf16 image that the 128x256-tile kernel of
+ * csrc/gemm_split.hip streams into LDS by DMA; exported for tests and for callers that compose their own step:
+ *   shivae_presplit_bytes   -- bytes of the image of an [N,K] weight matrix
+ *   shivae_presplit_weights -- W[N][ldw] (fp32, K used) -> image
+ *   shivae_gemm_nt_presplit -- C[M,N] = epilogue(A[M,K] W[N,K]^T) with W given as its image; N % 256 == 0, K % 4 == 0,
+ *                              K >= 32, M > 64, 16-B aligned operands; epi as shivae_gemm (no softplus). */
+size_t shivae_presplit_bytes(int N, int K);
+int shivae_presplit_weights(const float* W_dev, int N, int K, int ldw, void* image_dev, shivae_stream stream);
+int shivae_gemm_nt_presplit(int M, int N, int K, const float* A, int lda, const void* image_dev, float* C, int ldc,
+                            const float* bias, const float* aux, int ldaux, int epi, int splitk, shivae_stream stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------ */
 int shivae_zero(float* buf_dev, int64_t n, shivae_stream stream);

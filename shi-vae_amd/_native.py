@@ -31,7 +31,7 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_init", "shivae_plan_se
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
            "shivae_plan_chunk_rows", "shivae_plan_observed_fraction", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
-           "shivae_set_gemm_split", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
+           "shivae_set_gemm_split", "shivae_presplit_bytes", "shivae_presplit_weights", "shivae_gemm_nt_presplit", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
            "shivae_allreduce_grads",
            "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
@@ -87,6 +87,10 @@ def lib():
     L.shivae_scan_bwd.argtypes = [vp, vp, vp, vp, cf, vp, vp, vp, vp, vp]
     L.shivae_loss_reduce.argtypes = [vp, cf, cf, vp, vp]
     L.shivae_set_gemm_split.argtypes = [ci]
+    L.shivae_presplit_bytes.argtypes = [ci, ci]
+    L.shivae_presplit_bytes.restype = C.c_size_t
+    L.shivae_presplit_weights.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.shivae_gemm_nt_presplit.argtypes = [ci, ci, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp]
     L.shivae_sqnorm_noalloc.argtypes = [vp, i64, vp, vp]
     L.shivae_comm_unique_id.argtypes = [vp]
     L.shivae_comm_init.argtypes = [C.POINTER(vp), ci, ci, vp]
@@ -198,7 +202,7 @@ def profile_name(i):
     if i < 18:
         return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 6], _TILES[i % 6])
     return {18: "scan_fwd_kernel", 19: "scan_bwd_kernel", 20: "heter_nll_kernel", 21: "kl_kernel", 22: "head_fwd_kernel",
-            23: "head_bwd_kernel"}[i]
+            23: "head_bwd_kernel", 24: "gemm_split_nt_kernel<128x256, pre-split W>"}[i]
 
 
 def profile_start():

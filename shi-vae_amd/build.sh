@@ -3,7 +3,7 @@
 set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/libshivae_hip.so"
-SRC="$HERE/csrc/gemm.hip $HERE/csrc/loss.hip $HERE/csrc/scan.hip $HERE/csrc/optim.hip $HERE/csrc/plan.hip $HERE/csrc/prep.hip $HERE/csrc/heads.hip"
+SRC="$HERE/csrc/gemm.hip $HERE/csrc/gemm_split.hip $HERE/csrc/loss.hip $HERE/csrc/scan.hip $HERE/csrc/optim.hip $HERE/csrc/plan.hip $HERE/csrc/prep.hip $HERE/csrc/heads.hip"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OBJ="$HERE/csrc/_obj"
 mkdir -p "$OBJ"

@@ -35,7 +35,7 @@ void set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
 // ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x128 split-bf16)
-enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_COUNT = 24 };
+enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_SPLITW_NT = 24, PROF_COUNT = 25 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);
 void prof_shape(int M, int N, int K, int G);  // optional detail for the next prof_begin
@@ -89,6 +89,7 @@ struct GemmDesc {
     int unaligned;  // 1: some group base pointer is not 16-B aligned -> scalar global loads
     int c_aligned;  // 1: every group's C (and aux) base is 16-B aligned (group tables; inline groups are checked)
     int ragged;     // GemmRagged bits: per-group device-side row counts and row lists (the mask-aware decoder)
+    int nimg;       // launch_gemm_split_nt: rows of the weight image B points into (0: = N)
 };
 
 extern unsigned long long* g_gemm_stamps;  // diagnostics: see shivae_debug_gemm_stamps
@@ -97,6 +98,15 @@ extern int g_gemm_split;                    // see shivae_set_gemm_split
 // groups_dev: device array of ngroups GemmGroup, or nullptr with ngroups==1 and g0 used.
 int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
                 hipStream_t stream);
+
+// ---- split-mode NT GEMM against pre-split weights (gemm_split.hip): GemmGroup::B = weight image
+bool gemm_split_on();                              // SHIVAE_GEMM_SPLIT / shivae_set_gemm_split, resolved
+size_t presplit_bytes(int N, int K);               // bytes of the image of one [N,K] weight matrix
+// img[b] = three-plane bf16 image of W[b] ([N,K] row-major, leading dimension ld); images are presplit_bytes apart
+int launch_presplit(const float* W, int N, int K, int ld, int batch, size_t in_stride, void* img, hipStream_t stream);
+bool split_nt_fits(const GemmDesc& d);
+int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                         hipStream_t stream);
 
 // bias gradient: out[g][n] += sum_m Y_g[m*ld + n]
 struct ColsumGroup {

@@ -77,11 +77,14 @@ constexpr int SPLIT_RS = 104;  // halves per row of the K-contiguous split image
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // {bf16 trunc(a), bf16 trunc(b)} as one dword
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302);
 }
+__device__ __forceinline__ float bf16_rn(float x) {  // x rounded to the nearest bf16 (ties to even), as a float
+    return (float)(__bf16)x;
+}
 __device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) {
-    hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
-    const float r = x - hi;
-    mid = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
-    lo = r - mid;  // (<= 8 significant bits left: its upper half is exact)
+    hi = bf16_rn(x);
+    const float r = x - hi;   // exact: at most 16 significant bits
+    mid = bf16_rn(r);
+    lo = r - mid;             // exact: at most 8 significant bits, so its upper half is all of it
 }
 
 template <bool KC, int ROWS, int NT, bool VEC, bool SPLIT = false>
@@ -438,6 +441,15 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
                 }
         }
     };
+    f32x16 acc2[SPLIT ? TM : 1][SPLIT ? TN : 1];  // split mode: the five correction products, kept apart from hi*hi
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+    }
     auto compute_split = [&](const float* sa, const float* sb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -454,11 +466,11 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
             for (int x = 0; x < TM; ++x)
 #pragma unroll
                 for (int y = 0; y < TN; ++y) {  // smallest terms first
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc[x][y], 0, 0, 0);
+                    acc2[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc2[x][y], 0, 0, 0);
+                    acc2[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc2[x][y], 0, 0, 0);
+                    acc2[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc2[x][y], 0, 0, 0);
+                    acc2[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc2[x][y], 0, 0, 0);
+                    acc2[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc2[x][y], 0, 0, 0);
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
                 }
         }
@@ -579,6 +591,14 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += acc2[a][b][r];
+    }
     const int epi = p.epi;
     constexpr int LDE = BN + 4;                              // padded row length of the staged tile
     constexpr int BANDS = WM * TM;                           // 32-row bands of the block tile
@@ -743,6 +763,10 @@ unsigned long long* g_gemm_stamps = nullptr;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int g_gemm_split = -1;  // -1: not set (SHIVAE_GEMM_SPLIT decides at the first launch), 0 / 1: shivae_set_gemm_split
+bool gemm_split_on() {
+    if (g_gemm_split < 0) { const char* f = getenv("SHIVAE_GEMM_SPLIT"); g_gemm_split = f ? atoi(f) != 0 : 0; }
+    return g_gemm_split > 0;
+}
 
 template <bool A_KC, bool B_KC, bool VEC, int WM, int WN, int TM, int TN, int MINB = (TM * TN <= 2 ? 4 : (TM * TN <= 4 ? 3 : 2)), bool DB = false,
           bool DMA = false, bool SPLIT = false>
@@ -795,7 +819,7 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
     static const int mode = [] { const char* f = getenv("SHIVAE_GEMM_TILE"); return f ? atoi(f) : 0; }();
     if (mode == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false>(p, ngroups, stream);  // 8 waves, 1 stage
     if constexpr (VEC) {
-        if (g_gemm_split < 0) { const char* f = getenv("SHIVAE_GEMM_SPLIT"); g_gemm_split = f ? atoi(f) != 0 : 0; }
+        (void)gemm_split_on();
         // split mode: fp32 products as six bf16 MFMAs (see TileLoader); 128 x 128, 8 waves, one LDS stage
         if (g_gemm_split > 0) {
             static const int st = [] { const char* f = getenv("SHIVAE_SPLIT_TILE"); return f ? atoi(f) : 0; }();
@@ -806,6 +830,10 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
                 // measured 7 % slower than 128 x 128 in the training step (144.7 against 155.9 TFLOP/s), kept for A/B runs
                 if (st == 4 && p.N % 256 == 0) return launch_cfg<A_KC, B_KC, VEC, 2, 4, 1, 2, 4, false, false, true>(p, ngroups, stream);
             }
+            // NT: 8 waves of 32 x 64 (both accumulator sets fit 128 registers, two workgroups per CU).  NN / TN: the
+            // row-contiguous fragments need more registers and spilled there (64-80 B per lane, TN 150 -> 90 TFLOP/s),
+            // so they run 4 waves of 64 x 64 at 256 registers, still two workgroups per CU
+            if constexpr (!B_KC) return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2, 2, false, false, true>(p, ngroups, stream);
             return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false, false, true>(p, ngroups, stream);
         }
         // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands

@@ -1,0 +1,392 @@
+// Split-mode NT GEMM against PRE-SPLIT weights: C[M,N] = epilogue(A[M,K] * W[N,K]^T), fp32 in / fp32 out, products on
+// the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
+//
+// The decoder's Linear layers (decoders.py:60-66,127-171) and their input gradients all multiply a tall activation
+// matrix by a weight matrix that is a PARAMETER: constant for the whole step and re-used by every row tile.  The
+// generic split kernel of gemm.hip re-splits both operands in every workgroup; here the weights are split once per
+// step into their three bf16 planes (presplit_kernel), stored in the order the tiles consume them, and then stream
+// into LDS by LDS-DMA with no register round trip and no arithmetic.  Only the activation tile is split in the kernel.
+//
+// Arithmetic (same contract as gemm.hip's split mode, see include/shivae_hip.h shivae_set_gemm_split):
+//   x = hi + mid + lo exactly, each term x rounded to the NEAREST bf16 of what is left (v_cvt_pk_bf16_f32);
+//   a*b ~ ah*bh  [main accumulator]  +  (ah*bm + am*bh + am*bm + ah*bl + al*bh)  [correction accumulator];
+//   the dropped terms (am*bl, al*bm, al*bl) are <= 2^-26 |a b|.  The corrections are <= 2^-8 of the product, so the
+//   roundings of THEIR running sum are invisible at fp32 level and the main sum takes one rounding per 16 products:
+//   measured error at or below the fp32-input MFMA's (tests/test_gpu_split_mode.py).
+//
+// Tile: 128 x 256 x 32 per workgroup of 8 waves (2 x 4, 64 x 64 per wave = 2 x 2 MFMA tiles, two accumulator sets =
+// 128 registers), one workgroup per CU, two LDS stages of 72 KiB (A 3 x 128 x 64 B + W 3 x 256 x 64 B), one barrier
+// per K-tile.  A 256-wide tile covers ALL output columns of the trunk's H = 256 layers, so their activation operand
+// is fetched exactly once.
+//
+// Weight image (global): [KT][3 planes][N][32 bf16], K zero-padded to a multiple of 32: the 256 rows of a column
+// tile are 16 KiB contiguous per (K-tile, plane), i.e. every 1-KiB LDS-DMA piece is one contiguous KiB of global memory.
+// LDS images (both operands): [plane][row][64 B], the four 16-B chunks of a row XOR-swizzled by (row >> 2) & 3 --
+// applied to the DMA's SOURCE address and to the fragment reads (cdna_hip_programming.md rule 21) -- so that the 16
+// lanes of a ds_read_b128 lane group hit 16 distinct 4-bank slots.
+#include <algorithm>
+
+#include "common.h"
+
+namespace shivae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* gbl_f32_ptr;
+typedef const __attribute__((address_space(1))) f32x4* gbl_f32x4_ptr;
+typedef const __attribute__((address_space(1))) int* gbl_i32_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+constexpr int SW_BM = 128, SW_BN = 256, SW_NT = 512;
+constexpr int SW_A_BYTES = 3 * SW_BM * 64;
+constexpr int SW_W_BYTES = 3 * SW_BN * 64;
+constexpr int SW_STAGE = SW_A_BYTES + SW_W_BYTES;
+constexpr int SW_LDS = 2 * SW_STAGE;  // 147 456 B
+constexpr int SW_LDE = SW_BN + 4;     // floats per row of the staged C tile (128 x 260 x 4 B = 133 120 B)
+static_assert(SW_BM * SW_LDE * 4 <= SW_LDS, "the staged C tile fits the K loop's LDS");
+
+size_t presplit_bytes(int N, int K) { return (size_t)ceil_div(K, 32) * 3 * (size_t)N * 64; }
+
+// ---------------------------------------------------------------- weights -> three bf16 planes, once per step
+// One thread per (row n, 8 consecutive k): coalesced fp32 reads along the row, one 16-B store per plane.
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ W, int N, int K, int ld, size_t in_stride,
+                                                       unsigned char* __restrict__ img, size_t out_stride) {
+    const int KT = (K + 31) >> 5, k8n = KT * 4;
+    const float* src = W + blockIdx.y * in_stride;
+    unsigned char* dst = img + blockIdx.y * out_stride;
+    const size_t total = (size_t)N * k8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / k8n), k8 = (int)(i % k8n), k0 = k8 * 8;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (k0 + c < K) ? src[(size_t)n * ld + k0 + c] : 0.f;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const __bf16 hb = (__bf16)v[c];
+            const float r = v[c] - (float)hb;
+            const __bf16 mb = (__bf16)r;
+            h[c] = hb; m[c] = mb; l[c] = (__bf16)(r - (float)mb);
+        }
+        const int kt = k8 >> 2, c4 = k8 & 3;
+        unsigned char* o = dst + ((size_t)kt * 3 * N + n) * 64 + c4 * 16;
+        *reinterpret_cast<bf16x8*>(o) = h;
+        *reinterpret_cast<bf16x8*>(o + (size_t)N * 64) = m;
+        *reinterpret_cast<bf16x8*>(o + (size_t)2 * N * 64) = l;
+    }
+}
+
+int launch_presplit(const float* W, int N, int K, int ld, int batch, size_t in_stride, void* img, hipStream_t stream) {
+    if (N <= 0 || K <= 0 || batch <= 0) return SHIVAE_OK;
+    SV_REQUIRE(batch <= 65535, "presplit: too many matrices");
+    SV_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "presplit: image must be 16-B aligned");
+    const size_t total = (size_t)N * ceil_div(K, 32) * 4;
+    const int gx = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(presplit_kernel, dim3(gx, batch), dim3(256), 0, stream, W, N, K, ld, in_stride,
+                       static_cast<unsigned char*>(img), presplit_bytes(N, K));
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// ---------------------------------------------------------------- the GEMM
+struct SplitNtParams {
+    int M, N, K, lda, ldc, ldaux, epi, ragged, splitk, kt_per_split, KT, Nimg;
+    int ntx, nty, nz;
+    const GemmGroup* groups;  // GemmGroup::B = the group's weight IMAGE (presplit_kernel), not fp32 weights
+    GemmGroup g0;
+};
+
+__device__ __forceinline__ GemmGroup sw_load_group(const SplitNtParams& p, int gi) {
+    if (!p.groups) return p.g0;
+    typedef const unsigned long long __attribute__((address_space(4))) * const_u64_ptr;
+    const_u64_ptr q = (const_u64_ptr)(uintptr_t)(p.groups + __builtin_amdgcn_readfirstlane(gi));
+    GemmGroup g;
+    g.A = reinterpret_cast<const float*>(q[0]);
+    g.B = reinterpret_cast<const float*>(q[1]);
+    g.C = reinterpret_cast<float*>(q[2]);
+    g.bias = reinterpret_cast<const float*>(q[3]);
+    g.aux = reinterpret_cast<const float*>(q[4]);
+    g.csum = reinterpret_cast<float*>(q[5]);
+    g.cnt = reinterpret_cast<const int*>(q[6]);
+    g.aidx = reinterpret_cast<const int*>(q[7]);
+    g.bidx = reinterpret_cast<const int*>(q[8]);
+    g.cidx = reinterpret_cast<const int*>(q[9]);
+    return g;
+}
+
+__device__ __forceinline__ void sw_gstore4(float* p, float a, float b, float c, float d) {
+    f32x4 t;
+    t.x = a; t.y = b; t.z = c; t.w = d;
+    *(__attribute__((address_space(1))) f32x4*)p = t;
+}
+__device__ __forceinline__ void sw_atomic_add(float* p, float v) {
+    __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SW_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3, li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id; the column tiles that share an
+    // activation tile get consecutive slots of ONE XCD, and consecutive row tiles of a group are dealt round the XCDs
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = slot % p.ntx, u = (slot / p.ntx) * 8 + xcd;
+    if (u >= p.nty * p.nz) return;
+    const int by = u % p.nty, bz = u / p.nty;
+    const int gidx = bz / p.splitk, ks = bz % p.splitk;
+    const GemmGroup g = sw_load_group(p, gidx);
+    const int m0 = by * SW_BM, n0 = bx * SW_BN;
+    int Mrows = p.M;
+    const int *aidx = nullptr, *cidx = nullptr;
+    if (p.ragged) {
+        if (p.ragged & RAG_CNT) {
+            typedef const int __attribute__((address_space(4))) * const_int_ptr;
+            Mrows = min(Mrows, *(const_int_ptr)(uintptr_t)g.cnt);
+        }
+        if (p.ragged & RAG_AIDX) aidx = g.aidx;
+        if (p.ragged & RAG_CIDX) cidx = g.cidx;
+    }
+    if (m0 >= Mrows) return;
+    const int kt0 = ks * p.kt_per_split, kt1 = min(p.KT, kt0 + p.kt_per_split);
+    if (kt0 >= kt1) return;  // (split-K launches are atomic: nothing to add)
+
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[x][y][r] = 0.f; cor[x][y][r] = 0.f; }
+
+    // ---- activation tile: thread -> rows ar, ar + 64, four consecutive k at 4 * akq
+    const int ar = tid >> 3, akq = tid & 7;
+    size_t abase[2];
+    bool aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = m0 + ar + 64 * i;
+        aok[i] = r < Mrows;
+        // (the list is read unconditionally -- a dummy word of A itself without one -- and selected afterwards)
+        const gbl_i32_ptr q = aidx ? (gbl_i32_ptr)aidx : (gbl_i32_ptr)g.A;
+        const int t = q[(aidx && aok[i]) ? r : 0];
+        abase[i] = (size_t)(aok[i] ? (aidx ? t : r) : 0) * p.lda;
+    }
+    const gbl_f32_ptr Ag = (gbl_f32_ptr)g.A;
+    auto loadA = [&](int kt, f32x4 (&v)[2]) {
+        const int k = kt * 32 + 4 * akq;
+        const bool kok = k < p.K;  // K % 4 == 0: a float4 is all-valid or all-invalid
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = aok[i] && kok;
+            const f32x4 t = *(gbl_f32x4_ptr)(Ag + (ok ? abase[i] + k : 0));
+            v[i] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // byte offset of this thread's 8-B piece inside one plane of the A image
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = ar + 64 * i;
+        aoff[i] = r * 64 + (((akq >> 1) ^ ((r >> 2) & 3)) << 4) + (akq & 1) * 8;
+    }
+    auto storeA = [&](unsigned char* ast, const f32x4 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x4 h = __builtin_convertvector(v[i], bf16x4);
+            const f32x4 r = v[i] - __builtin_convertvector(h, f32x4);
+            const bf16x4 m = __builtin_convertvector(r, bf16x4);
+            const bf16x4 l = __builtin_convertvector(r - __builtin_convertvector(m, f32x4), bf16x4);
+            *reinterpret_cast<bf16x4*>(ast + aoff[i]) = h;
+            *reinterpret_cast<bf16x4*>(ast + SW_BM * 64 + aoff[i]) = m;
+            *reinterpret_cast<bf16x4*>(ast + 2 * SW_BM * 64 + aoff[i]) = l;
+        }
+    };
+
+    // ---- weight tile by LDS-DMA: 48 pieces of 1 KiB (3 planes x 16 blocks of 16 rows), 6 per wave
+    const unsigned char* Wimg = reinterpret_cast<const unsigned char*>(g.B);
+    const int wrow = lane >> 2, wc4 = lane & 3;
+    auto dmaW = [&](int kt, unsigned char* wst) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int pc = wid + 8 * j, pl = pc >> 4, row = (pc & 15) * 16 + wrow;
+            const unsigned char* src =
+                Wimg + ((size_t)(kt * 3 + pl) * p.Nimg + n0 + row) * 64 + ((wc4 ^ ((row >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(wst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragments: 8 consecutive k (16 B) of one row and plane; row-dependent parts hoisted
+    int fa[2], fb[2], sa[2], sb[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int ra = wm * 64 + x * 32 + li, rb = wn * 64 + x * 32 + li;
+        fa[x] = ra * 64; sa[x] = (ra >> 2) & 3;
+        fb[x] = rb * 64; sb[x] = (rb >> 2) & 3;
+    }
+    auto compute = [&](const unsigned char* ast, const unsigned char* wst) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2][3], b[2][3];
+            const int c = 2 * s + lh;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[x][pl] = *reinterpret_cast<const bf16x8*>(ast + pl * SW_BM * 64 + fa[x] + ((c ^ sa[x]) << 4));
+                    b[x][pl] = *reinterpret_cast<const bf16x8*>(wst + pl * SW_BN * 64 + fb[x] + ((c ^ sb[x]) << 4));
+                }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {  // corrections smallest first; the leading product on its own
+                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], cor[x][y], 0, 0, 0);
+                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], cor[x][y], 0, 0, 0);
+                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], cor[x][y], 0, 0, 0);
+                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], cor[x][y], 0, 0, 0);
+                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], cor[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- K loop: two stages, one barrier per K-tile; the next tile's activations travel through registers and are
+    //      split behind this tile's MFMAs, its weights stream in by DMA meanwhile
+    f32x4 va[2];
+    loadA(kt0, va);
+    dmaW(kt0, lds + SW_A_BYTES);
+    storeA(lds, va);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0, kt = kt0;
+    for (; kt + 1 < kt1; ++kt) {
+        unsigned char* nxt = lds + (cur ^ 1) * SW_STAGE;
+        loadA(kt + 1, va);
+        dmaW(kt + 1, nxt + SW_A_BYTES);
+        compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
+        storeA(nxt, va);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
+    __syncthreads();
+
+    // ---- epilogue: the whole C tile is staged in LDS once, then every thread handles 16-B pieces of whole rows
+    float* cst = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cst[(wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SW_LDE + wn * 64 + y * 32 + li] =
+                    acc[x][y][r] + cor[x][y][r];
+    __syncthreads();
+    const int epi = p.epi;
+    const int c4 = tid & 63, col = n0 + c4 * 4, rw = tid >> 6;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi & EPI_BIAS) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bias4[c] = *((gbl_f32_ptr)g.bias + col + c);
+    }
+    constexpr int CH = 4;  // pieces in flight per thread (gate / old-C loads of a round are requested together)
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += CH) {
+        f32x4 v[CH], ax[CH], cold[CH];
+        bool ok[CH];
+        size_t off[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int lr = rw + 8 * (i0 + i), row = m0 + lr;
+            ok[i] = row < Mrows;
+            const int crow = cidx ? ((gbl_i32_ptr)cidx)[ok[i] ? row : 0] : row;
+            off[i] = ok[i] ? (size_t)crow * p.ldc + col : 0;
+            v[i] = *reinterpret_cast<const f32x4*>(cst + lr * SW_LDE + c4 * 4);
+            if (epi & EPI_MASK) ax[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
+            if (epi & EPI_ADDC) cold[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.C + off[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (!ok[i]) continue;
+            float* cp = g.C + off[i];
+            float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            if (epi & EPI_ATOMIC) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sw_atomic_add(cp + c, e[c]);
+                continue;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] += bias4[c];
+            if (epi & EPI_ADDC) { e[0] += cold[i].x; e[1] += cold[i].y; e[2] += cold[i].z; e[3] += cold[i].w; }
+            if (epi & EPI_RELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[c] = fmaxf(e[c], 0.f);
+            }
+            if (epi & EPI_MASK) {
+                e[0] = ax[i].x > 0.f ? e[0] : 0.f; e[1] = ax[i].y > 0.f ? e[1] : 0.f;
+                e[2] = ax[i].z > 0.f ? e[2] : 0.f; e[3] = ax[i].w > 0.f ? e[3] : 0.f;
+            }
+            sw_gstore4(cp, e[0], e[1], e[2], e[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cs4[c] += e[c];
+        }
+    }
+    if (epi & EPI_COLSUM) {
+        // the 8 waves hold partial sums of the same 256 columns: meet in LDS, one atomic per column and tile
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(cst + rw * SW_BN + c4 * 4) = (f32x4){cs4[0], cs4[1], cs4[2], cs4[3]};
+        __syncthreads();
+        if (tid < SW_BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += cst[k * SW_BN + tid];
+            sw_atomic_add(g.csum + n0 + tid, t);
+        }
+    }
+}
+
+static bool sw_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// Shapes this kernel takes (everything else stays on gemm.hip's kernels)
+bool split_nt_fits(const GemmDesc& d) {
+    return d.layout == GEMM_NT && d.N >= SW_BN && d.N % SW_BN == 0 && d.K % 4 == 0 && d.K >= 32 && d.lda % 4 == 0 &&
+           d.ldc % 4 == 0 && (!(d.epi & EPI_MASK) || d.ldaux % 4 == 0) && !(d.epi & EPI_SOFTPLUS) && !d.unaligned &&
+           !(d.ragged & RAG_BIDX) && d.M > 64;
+}
+
+int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                         hipStream_t stream) {
+    if (d.M <= 0 || d.N <= 0 || ngroups <= 0) return SHIVAE_OK;
+    SV_REQUIRE(split_nt_fits(d), "gemm_split_nt: shape M=%d N=%d K=%d not supported", d.M, d.N, d.K);
+    SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "gemm_split_nt: %d groups need a device group table", ngroups);
+    SV_REQUIRE(d.splitk >= 1 && (d.splitk == 1 || d.epi == EPI_ATOMIC), "gemm_split_nt: split-K needs the atomic epilogue");
+    SV_REQUIRE(!(d.epi & EPI_ATOMIC) || d.epi == EPI_ATOMIC, "gemm_split_nt: atomic epilogue excludes the others");
+    SV_REQUIRE(!d.ragged || groups_dev != nullptr, "gemm_split_nt: ragged launches take a device group table");
+    if (!groups_dev)
+        SV_REQUIRE(sw_aligned16(g0.A) && sw_aligned16(g0.B) && sw_aligned16(g0.C) && (!(d.epi & EPI_MASK) || sw_aligned16(g0.aux)),
+                   "gemm_split_nt: operands must be 16-B aligned");
+    SplitNtParams p;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldc = d.ldc; p.ldaux = d.ldaux; p.epi = d.epi; p.ragged = d.ragged;
+    p.splitk = d.splitk;
+    p.KT = ceil_div(d.K, 32);
+    p.Nimg = d.nimg > 0 ? d.nimg : d.N;
+    SV_REQUIRE(p.Nimg >= d.N, "gemm_split_nt: image has %d rows, N = %d", p.Nimg, d.N);
+    p.kt_per_split = ceil_div(p.KT, d.splitk);
+    p.ntx = d.N / SW_BN; p.nty = ceil_div(d.M, SW_BM); p.nz = ngroups * d.splitk;
+    p.groups = groups_dev; p.g0 = g0;
+    const long long units = (long long)p.nty * p.nz;
+    const long long nblocks = (units + 7) / 8 * 8 * p.ntx;
+    SV_REQUIRE(nblocks < (1ll << 31), "gemm_split_nt: grid too large");
+    prof_shape(d.M, d.N, d.K, ngroups);
+    prof_begin(PROF_SPLITW_NT, 2.0 * d.M * d.N * (double)d.K * ngroups, stream);
+    hipLaunchKernelGGL(gemm_split_nt_kernel, dim3((unsigned)nblocks), dim3(SW_NT), 0, stream, p);
+    prof_end(stream);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+}  // namespace shivae

@@ -74,6 +74,7 @@ struct GroupTable {  // device table of GemmGroup + matching bias-gradient table
     int unaligned = 0;
     int c_aligned = 1;
     std::vector<int> attr;  // attribute of each group (ragged launches: whose row count applies)
+    GemmGroup* dev_img = nullptr;  // the same groups with B = the weight's pre-split image (gemm_split.hip), or null
 };
 struct ColTable {
     ColsumGroup* dev = nullptr;
@@ -259,6 +260,12 @@ static void build_workspace(shivae_plan* p) {
     carve(p, "wt2", D * 2 * H * H, cur);
     carve(p, "wt4", D * H * H, cur);
     carve(p, "wth0", (size_t)std::max(p->nbc, 1) * H * H, cur);
+    // pre-split bf16 images of the same weights and of their transposes (split mode, gemm_split.hip)
+    auto img = [&](const char* name, size_t count, int N, int K) { carve(p, name, count * presplit_bytes(N, K) / sizeof(float), cur); };
+    img("wi_f0", D, 2 * p->H, p->E); img("wi_f2", D, p->H, 2 * p->H); img("wi_f4", D, p->H, p->H);
+    img("wi_fh0", std::max(p->nbc, 1), p->H, p->H);
+    img("wi_t0", 1, p->E, p->D * 2 * p->H); img("wi_t2", D, 2 * p->H, p->H); img("wi_t4", D, p->H, p->H);
+    img("wi_th0", std::max(p->nbc, 1), p->H, p->H);
     p->ws_bytes = cur;
 }
 
@@ -375,6 +382,15 @@ static int build_tables(shivae_plan* p) {
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     const float* embc = p->wsf("embc");
     std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, dl0, dl0r, wl1, dl1, wl2, dl2, wh0, dh0;
+    std::vector<GemmGroup> fl0i, fl1i, fl2i, fh0i, dl1i, dl2i, dh0i;  // B = pre-split weight image
+    auto IMG = [&](const char* name, size_t idx, int N, int K) {
+        return reinterpret_cast<const float*>(p->ws + p->ws_off.at(name) + idx * presplit_bytes(N, K));
+    };
+    auto twin = [&](std::vector<GemmGroup>& dst, const GemmGroup& src, const float* image) {
+        GemmGroup t = src;
+        t.B = image;
+        dst.push_back(t);
+    };
     float* dembc = p->wsf("dembc");
     {
         // a few columns past a multiple of 128 (E = 528) go to a skinny launch of their own, as in gemm1
@@ -411,6 +427,9 @@ static int build_tables(shivae_plan* p) {
             dl0r.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, dembc + p->l0_nmain, nullptr, nullptr, nullptr, nullptr, nullptr, list));
         fl1.push_back(G(a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr, nullptr));
         fl2.push_back(G(a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr, nullptr));
+        twin(fl0i, fl0.back(), IMG("wi_f0", d, 2 * H, p->E));
+        twin(fl1i, fl1.back(), IMG("wi_f2", d, H, 2 * H));
+        twin(fl2i, fl2.back(), IMG("wi_f4", d, H, H));
         wl2.push_back(G(da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr, nullptr));
         dl2.push_back(G(da2d, p->wsf("wt4") + (size_t)d * H * H, da1d, nullptr, a1d, GA(SHIVAE_P_DEC2_B, d)));
         wl1.push_back(G(da1d, a0d, GA(SHIVAE_P_DEC2_W, d), nullptr, nullptr, nullptr));
@@ -418,6 +437,8 @@ static int build_tables(shivae_plan* p) {
         // back to chunk rows)
         dl1.push_back(G(da1d, p->wsf("wt2") + (size_t)d * 2 * H * H, da0d, nullptr, a0d,
                         p->grads + p->glob[SHIVAE_P_DEC0_B].off + (size_t)d * 2 * H, nullptr, nullptr, list));
+        twin(dl2i, dl2.back(), IMG("wi_t4", d, H, H));
+        twin(dl1i, dl1.back(), IMG("wi_t2", d, 2 * H, H));
         // heads (decoders.py:69-102)
         float* wout = p->params + p->glob[SHIVAE_P_HEADOUT_W].off + (size_t)a.poff * H;
         float* bout = p->params + p->glob[SHIVAE_P_HEADOUT_B].off + a.poff;
@@ -433,6 +454,8 @@ static int build_tables(shivae_plan* p) {
             fh0.push_back(G(a2d, PA(SHIVAE_P_HEAD0_W, d), hhj, PA(SHIVAE_P_HEAD0_B, d), nullptr, nullptr));
             wh0.push_back(G(dhhj, a2d, GA(SHIVAE_P_HEAD0_W, d), nullptr, nullptr, nullptr));
             dh0.push_back(G(dhhj, p->wsf("wth0") + (size_t)jx * H * H, da2d, nullptr, a2d, GA(SHIVAE_P_DEC4_B, d)));
+            twin(fh0i, fh0.back(), IMG("wi_fh0", jx, H, H));
+            twin(dh0i, dh0.back(), IMG("wi_th0", jx, H, H));
             hin = hhj; dhin = dhhj; hmask = hhj; dhbias = GA(SHIVAE_P_HEAD0_B, d);
         }
         // tables are keyed by +nout (input = hh, bin/cat) or -nout (input = a2, real/pos): the two
@@ -454,6 +477,10 @@ static int build_tables(shivae_plan* p) {
     SV_TRY(make_table(p, wl1, p->b_l1_w, all)); SV_TRY(make_table(p, dl1, p->b_l1_d, all));
     SV_TRY(make_table(p, wl2, p->b_l2_w, all)); SV_TRY(make_table(p, dl2, p->b_l2_d, all));
     SV_TRY(make_table(p, wh0, p->b_h0_w, bc)); SV_TRY(make_table(p, dh0, p->b_h0_d, bc));
+    SV_TRY(upload(p, fl0i, &p->f_l0.dev_img)); SV_TRY(upload(p, fl1i, &p->f_l1.dev_img));
+    SV_TRY(upload(p, fl2i, &p->f_l2.dev_img)); SV_TRY(upload(p, fh0i, &p->f_h0.dev_img));
+    SV_TRY(upload(p, dl1i, &p->b_l1_d.dev_img)); SV_TRY(upload(p, dl2i, &p->b_l2_d.dev_img));
+    SV_TRY(upload(p, dh0i, &p->b_h0_d.dev_img));
     for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first], ko[kv.first]));
     for (auto& kv : wo) SV_TRY(make_table(p, kv.second, p->b_out_w[kv.first], ko[kv.first]));
     for (auto& kv : dO) SV_TRY(make_table(p, kv.second, p->b_out_d[kv.first], ko[kv.first]));
@@ -502,13 +529,14 @@ static bool use_addc() {
 }
 
 static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                 const float* bias, const float* aux, int ldaux, int epi, hipStream_t s) {
+                 const float* bias, const float* aux, int ldaux, int epi, hipStream_t s, const void* Bimg = nullptr,
+                 int nimg = 0) {
     // A few columns past a multiple of 128 (E = 2H+K = 528 at H=256, K=16) would cost a whole extra
     // 128-wide tile column: run them as a separate skinny launch instead.
     const int rem = N % 128;
     if (N > 128 && rem > 0 && rem <= 32 && M > 64) {
         const int Nm = N - rem;
-        SV_TRY(gemm1(layout, M, Nm, K, A, lda, B, ldb, C, ldc, bias, aux, ldaux, epi, s));
+        SV_TRY(gemm1(layout, M, Nm, K, A, lda, B, ldb, C, ldc, bias, aux, ldaux, epi, s, Bimg, nimg));
         const float* B2 = layout == GEMM_NT ? B + (size_t)Nm * ldb : B + Nm;
         if (epi == 0 && K >= 4096) {
             // long-K skinny remainder: too few tiles to fill the chip -> zero the columns, split K, add atomically
@@ -541,6 +569,13 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
         }
     }
     GemmGroup g{A, B, C, bias, aux};
+    if (Bimg && gemm_split_on()) {  // split mode against the weight's pre-split image (gemm_split.hip)
+        d.nimg = nimg;
+        if (split_nt_fits(d) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(aux)) & 15) == 0) {
+            g.B = static_cast<const float*>(Bimg);
+            return launch_gemm_split_nt(d, nullptr, 1, g, s);
+        }
+    }
     return launch_gemm(d, nullptr, 1, g, s);
 }
 // rag_cnt: pinned host copy of the chunk's row counts while profiling (else null); see prof_ragged
@@ -555,6 +590,8 @@ static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int
         if (d.splitk == 1 && use_addc()) d.epi = EPI_ADDC;
     }
     if ((ragged & RAG_CNT) && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, layout == GEMM_TN ? K : M);
+    if (t.dev_img && gemm_split_on() && t.c_aligned && split_nt_fits(d))
+        return launch_gemm_split_nt(d, t.dev_img, t.n, GemmGroup{}, s);
     return launch_gemm(d, t.dev, t.n, GemmGroup{}, s);
 }
 // streaming heads (heads.hip) with their profile record: algorithmic bytes = one read of the head input (+ one
@@ -706,12 +743,25 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
     const Tensor* g = p->glob;
     const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
+    const bool split = gemm_split_on();
+    if (split) {  // the step's weights as three bf16 planes, once (gemm_split.hip)
+        SV_TRY(launch_presplit(p->prm(g[SHIVAE_P_DEC0_W]), 2 * H, E, E, D, (size_t)2 * H * E, p->wsf("wi_f0"), s));
+        SV_TRY(launch_presplit(p->prm(g[SHIVAE_P_DEC2_W]), H, 2 * H, 2 * H, D, (size_t)H * 2 * H, p->wsf("wi_f2"), s));
+        SV_TRY(launch_presplit(p->prm(g[SHIVAE_P_DEC4_W]), H, H, H, D, (size_t)H * H, p->wsf("wi_f4"), s));
+        if (p->nbc > 0) SV_TRY(launch_presplit(p->prm(g[SHIVAE_P_HEAD0_W]), H, H, H, p->nbc, (size_t)H * H, p->wsf("wi_fh0"), s));
+    }
     if (grad) {  // K-contiguous copies of the decoder weights for the input-gradient GEMMs
         SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC0_W]), p->wsf("wt0"), D * 2 * H, E, 1, 0, 0, s));
         SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC2_W]), p->wsf("wt2"), H, 2 * H, D, (size_t)H * 2 * H, (size_t)H * 2 * H, s));
         SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_DEC4_W]), p->wsf("wt4"), H, H, D, (size_t)H * H, (size_t)H * H, s));
         if (p->nbc > 0)
             SV_TRY(launch_transpose(p->prm(g[SHIVAE_P_HEAD0_W]), p->wsf("wth0"), H, H, p->nbc, (size_t)H * H, (size_t)H * H, s));
+        if (split) {
+            SV_TRY(launch_presplit(p->wsf("wt0"), E, D * 2 * H, D * 2 * H, 1, 0, p->wsf("wi_t0"), s));
+            SV_TRY(launch_presplit(p->wsf("wt2"), 2 * H, H, H, D, (size_t)2 * H * H, p->wsf("wi_t2"), s));
+            SV_TRY(launch_presplit(p->wsf("wt4"), H, H, H, D, (size_t)H * H, p->wsf("wi_t4"), s));
+            if (p->nbc > 0) SV_TRY(launch_presplit(p->wsf("wth0"), H, H, H, p->nbc, (size_t)H * H, p->wsf("wi_th0"), s));
+        }
     }
     float *embc = p->wsf("embc"), *dembc = p->wsf("dembc");
     float *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
@@ -750,6 +800,9 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
                 p->obs_frac = (float)(tot / ((double)D * rc));
             }
             SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, RAG_CNT | RAG_AIDX));
+        } else if (split && p->f_l0.dev_img && (2 * H) % 256 == 0 && E % 4 == 0 && rc > 64) {
+            // dense rows, split mode: the same grouped launch over all rows (the weight images are per attribute)
+            SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, 0));
         } else {
             // decoder forward: layer 0 of all attributes is one GEMM (shared input, stacked weights)
             SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
@@ -831,7 +884,8 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
             if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_dr, s, RAG_CNT | RAG_CIDX, true));
         } else {
-            SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s));
+            SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s,
+                         p->wsf("wi_t0"), E));
         }
 
         SV_TRY(launch_expand_add_emb(dembc, E4, H, K, d_emb + (size_t)r0 * Ep, Ep, Hp, Kp, rc, s));
@@ -1335,6 +1389,25 @@ int shivae_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
     GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0, 0};
     GemmGroup g{A, B, C, bias, aux};
     return launch_gemm(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
+}
+
+size_t shivae_presplit_bytes(int N, int K) { return (N > 0 && K > 0) ? presplit_bytes(N, K) : 0; }
+
+int shivae_presplit_weights(const float* W, int N, int K, int ldw, void* image, shivae_stream stream) {
+    SV_REQUIRE(W && image && N > 0 && K > 0 && ldw >= K, "presplit_weights: bad argument");
+    return launch_presplit(W, N, K, ldw, 1, 0, image, static_cast<hipStream_t>(stream));
+}
+
+int shivae_gemm_nt_presplit(int M, int N, int K, const float* A, int lda, const void* image, float* C, int ldc,
+                            const float* bias, const float* aux, int ldaux, int epi, int splitk, shivae_stream stream) {
+    SV_REQUIRE(A && image && C, "gemm_nt_presplit: null operand");
+    SV_REQUIRE(!(epi & EPI_BIAS) || bias, "gemm_nt_presplit: bias epilogue without bias");
+    SV_REQUIRE(!(epi & EPI_MASK) || aux, "gemm_nt_presplit: mask epilogue without aux");
+    GemmDesc d{GEMM_NT, M, N, K, lda, K, ldc, ldaux, epi, splitk < 1 ? 1 : splitk, 0, 0, 0, N};
+    SV_REQUIRE(split_nt_fits(d), "gemm_nt_presplit: needs N %% 256 == 0, K %% 4 == 0, K >= 32, M > 64, lda / ldc / ldaux %% 4 == 0 "
+               "(M=%d N=%d K=%d)", M, N, K);
+    GemmGroup g{A, static_cast<const float*>(image), C, bias, aux};
+    return launch_gemm_split_nt(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
 }
 
 int shivae_profile_start(void) {
