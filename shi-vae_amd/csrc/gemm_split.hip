@@ -25,6 +25,7 @@
 // applied to the DMA's SOURCE address and to the fragment reads (cdna_hip_programming.md rule 21) -- so that the 16
 // lanes of a ds_read_b128 lane group hit 16 distinct 4-bank slots.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -117,6 +118,24 @@ __device__ __forceinline__ GemmGroup sw_load_group(const SplitNtParams& p, int g
     return g;
 }
 
+// A 16-B global load the COMPILER DOES NOT TRACK: hipcc answers any register dependency on a load with
+// `s_waitcnt vmcnt(0)` while LDS-DMAs are in flight beside it (it takes the two kinds to complete out of order), which
+// would make every use of a prefetched activation wait for the DMAs and loads issued after it.  The K loop therefore
+// issues these loads by hand and waits for them by hand (sw_wait_loads), counting in issue order.
+__device__ __forceinline__ f32x4 sw_load16_untracked(const float* ptr) {
+    f32x4 v;
+    // (s_nop: the address registers were just written by a VALU instruction; the compiler pads that hazard for its own
+    // loads -- `s_nop 0` between v_lshl_add_u64 and global_load -- but does not look inside inline assembly)
+    asm volatile("s_nop 1\n\tglobal_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// wait until at most N vector-memory operations of this wave are outstanding; the registers pass through so that no
+// use of them can move above the wait
+template <int N>
+__device__ __forceinline__ void sw_wait_loads(f32x4 (&v)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N) : "memory");
+}
+
 __device__ __forceinline__ void sw_gstore4(float* p, float a, float b, float c, float d) {
     f32x4 t;
     t.x = a; t.y = b; t.z = c; t.w = d;
@@ -182,8 +201,9 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool ok = aok[i] && kok;
-            const f32x4 t = *(gbl_f32x4_ptr)(Ag + (ok ? abase[i] + k : 0));
-            v[i] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (always issued -- the K loop's waits count on exactly two loads per call -- and kept RAW: storeA zeroes
+            // what is not live)
+            v[i] = sw_load16_untracked(g.A + (ok ? abase[i] + k : 0));
         }
     };
     // byte offset of this thread's 8-B piece inside one plane of the A image
@@ -193,11 +213,16 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         const int r = ar + 64 * i;
         aoff[i] = r * 64 + (((akq >> 1) ^ ((r >> 2) & 3)) << 4) + (akq & 1) * 8;
     }
-    auto storeA = [&](unsigned char* ast, const f32x4 (&v)[2]) {
+    auto storeA = [&](unsigned char* ast, const f32x4 (&vr)[2], int kt) {
+        const bool kok = kt * 32 + 4 * akq < p.K;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16x4 h = __builtin_convertvector(v[i], bf16x4);
-            const f32x4 r = v[i] - __builtin_convertvector(h, f32x4);
+            const f32x4 t = vr[i];
+            const bool ok = aok[i] && kok;
+            f32x4 v1;
+            v1.x = ok ? t.x : 0.f; v1.y = ok ? t.y : 0.f; v1.z = ok ? t.z : 0.f; v1.w = ok ? t.w : 0.f;
+            const bf16x4 h = __builtin_convertvector(v1, bf16x4);
+            const f32x4 r = v1 - __builtin_convertvector(h, f32x4);
             const bf16x4 m = __builtin_convertvector(r, bf16x4);
             const bf16x4 l = __builtin_convertvector(r - __builtin_convertvector(m, f32x4), bf16x4);
             *reinterpret_cast<bf16x4*>(ast + aoff[i]) = h;
@@ -255,24 +280,48 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
 
     // ---- K loop: two stages, one barrier per K-tile; the next tile's activations travel through registers and are
     //      split behind this tile's MFMAs, its weights stream in by DMA meanwhile
-    f32x4 va[2];
-    loadA(kt0, va);
+    // Activations are requested TWO K-tiles ahead (two register sets that swap roles -- a copy would have to wait for
+    // the loads just requested); the weights' DMAs one K-tile ahead.  In every iteration the DMAs are issued first
+    // and the two activation loads last, so `s_waitcnt vmcnt(2)` means "my DMAs have landed" and lets the loads fly on.
+    // All waits on vector memory inside the loop are written by hand (see sw_load16_untracked).
+    f32x4 va[2], vb[2];
     dmaW(kt0, lds + SW_A_BYTES);
-    storeA(lds, va);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    loadA(kt0, vb);
+    loadA(kt0 + 1, va);
+    sw_wait_loads<2>(vb);  // (vb is younger than the DMAs: they have landed too; va's two loads fly on)
+    storeA(lds, vb, kt0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (bare: __syncthreads() carries a fence that waits for ALL vector-memory operations)
+    asm volatile("" ::: "memory");
     int cur = 0, kt = kt0;
-    for (; kt + 1 < kt1; ++kt) {
+    // One iteration = 6 DMAs, then 2 loads, in that order.  `vs` was requested one iteration ago, so 8 younger
+    // operations may still be outstanding when it is split; at the barrier the 2 loads of this iteration may.
+    auto iter = [&](int k, f32x4 (&vs)[2], f32x4 (&vl)[2]) {
         unsigned char* nxt = lds + (cur ^ 1) * SW_STAGE;
-        loadA(kt + 1, va);
-        dmaW(kt + 1, nxt + SW_A_BYTES);
+        dmaW(k + 1, nxt + SW_A_BYTES);
+        loadA(k + 2, vl);
+        __builtin_amdgcn_sched_barrier(0);  // (the requests go out before the MFMAs, not behind them)
         compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
-        storeA(nxt, va);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        sw_wait_loads<8>(vs);
+        storeA(nxt, vs, k + 1);
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         cur ^= 1;
+    };
+    for (; kt + 2 < kt1; kt += 2) {
+        iter(kt, va, vb);
+        iter(kt + 1, vb, va);
+    }
+    if (kt + 1 < kt1) {
+        iter(kt, va, vb);  // (vb receives K-tile kt+2 = past the range: never used)
+        ++kt;
     }
     compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
+    // Untracked loads whose data is never used (K-tiles past the range) still write their registers when they land:
+    // the registers must stay reserved until then, or the allocator hands them to a ds_read / MFMA operand that the
+    // late write then clobbers.  Hence: wait for everything, then a (void) use of both sets.
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]) : "memory");
     __syncthreads();
 
     // ---- epilogue: the whole C tile is staged in LDS once, then every thread handles 16-B pieces of whole rows
