@@ -50,6 +50,15 @@ CONFIGS = {
     "cfg5": (52, 51, 51, [8] * 358, 1000, 8192, 256, 64, 16, 0.9),       # categorical-heavy, 90 % missing
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+# split arithmetic: an fp32 product = 6 bf16 MFMA products, so its ceiling is the dense bf16 MFMA peak (~2.5 PFLOP/s,
+# same guide) / 6, in fp32-equivalent flops
+PEAK_SPLIT_TFLOPS = 2500.0 / 6.0
+ARITH = {
+    "split": "fp32 in / fp32 out; every fp32 operand split exactly into 3 bf16 terms (nearest), 6 bf16 MFMA products per "
+             "fp32 product, leading product and corrections in separate fp32 accumulators (shivae_set_gemm_split(1)); "
+             "error <= the fp32-input MFMA's on adversarial operands (tests/test_gpu_split_mode.py)",
+    "f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; shivae_set_gemm_split(0))",
+}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -194,8 +203,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-step", action="store_true",
                     help="skip the warm-up step under the library's HIP events (runs under rocprofv3 --pmc)")
-    ap.add_argument("--no-split-mode", action="store_true",
-                    help="skip the extra timing of the split-bf16 GEMM mode (reported next to the fp32-MFMA headline)")
+    ap.add_argument("--arith", choices=["split", "f32"], default=os.environ.get("SHIVAE_BENCH_ARITH", "split"),
+                    help="arithmetic of the decoder GEMMs in the timed steps (both compute fp32 products of fp32 data)")
+    ap.add_argument("--no-other-mode", "--no-split-mode", dest="no_other_mode", action="store_true",
+                    help="skip the short comparison leg in the other arithmetic (reported beside the headline)")
     ap.add_argument("--budget", type=float, default=float(os.environ.get("SHIVAE_BENCH_BUDGET_S", "480")),
                     help="wall-clock seconds for the whole process; counts are clamped to fit")
     a = ap.parse_args()
@@ -243,6 +254,7 @@ def main():
     model.check_nan = False
     model.overlap_allreduce = True  # N > 1: the decoder's gradient buckets start before the reverse-time scan
     model.train()
+    N.lib().shivae_set_gemm_split(1 if a.arith == "split" else 0)
     opt = shivae_amd.FusedClipAdam(model, lr=5e-3, clip=0.5)
     # one global batch (seed 1234), sharded by sequence: blocks of `blk` sequences have their own generator streams
     blk = max(1, math.gcd(512, B // 16)) if B % 16 == 0 else B
@@ -319,14 +331,15 @@ def main():
         say("profiled warm-up step: %.3f s" % prof_dt)
 
     # ---- how many more steps fit the budget (same decision on every rank)
-    # (the split-bf16 mode is timed afterwards on 1 warm-up + 3 steps of ~0.8 of an fp32 step each, when that fits
-    # next to at least 4 fp32 steps)
+    # (the other arithmetic is timed afterwards on 1 warm-up + 1 step, when that fits next to at least 8 headline steps;
+    # an fp32-MFMA step takes ~1.35 split steps)
     left = a.budget - (time.perf_counter() - T_PROC0) - 5.0
-    want_split = not a.no_split_mode and not a.no_profile_step
-    split_cost = 4 * 0.8 * prof_dt if want_split else 0.0
-    if want_split and (left - split_cost) / (prof_dt * 1.02) < min(a.steps, 4):
-        want_split, split_cost = False, 0.0
-    left -= split_cost
+    other = "f32" if a.arith == "split" else "split"
+    want_other = not a.no_other_mode and not a.no_profile_step
+    other_cost = 2 * (1.4 if other == "f32" else 0.8) * prof_dt if want_other else 0.0
+    if want_other and (left - other_cost) / (prof_dt * 1.02) < min(a.steps, 8):
+        want_other, other_cost = False, 0.0
+    left -= other_cost
     afford = int(left / (prof_dt * 1.02))
     if dist is not None:
         tt = torch.tensor([afford], device="cuda", dtype=torch.int64)
@@ -349,28 +362,26 @@ def main():
         marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
-    # ---- the same step with the decoder GEMMs in split-bf16 arithmetic (exact 3-way bf16 split of every fp32 operand,
-    #      six bf16 MFMA products per fp32 product, fp32 accumulation; shivae_set_gemm_split).  Reported beside the
-    #      headline, never instead of it.
+    # ---- the same step in the OTHER arithmetic of the decoder GEMMs, reported beside the headline, never instead of it
     split_times = []
     if dist is not None:
-        ws = torch.tensor([1 if want_split else 0], device="cuda")
+        ws = torch.tensor([1 if want_other else 0], device="cuda")
         dist.all_reduce(ws, op=dist.ReduceOp.MIN)
-        want_split = bool(int(ws))
-    if want_split:
-        N.lib().shivae_set_gemm_split(1)
+        want_other = bool(int(ws))
+    if want_other:
+        N.lib().shivae_set_gemm_split(1 if other == "split" else 0)
         step()
         fence()
         m0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(1):
             loss_s = step()
             torch.cuda.synchronize()
             m1 = time.perf_counter()
             split_times.append(m1 - m0)
             m0 = m1
         fence()
-        N.lib().shivae_set_gemm_split(0)
-        say("split-bf16 mode: %s s" % ", ".join("%.3f" % t for t in split_times))
+        N.lib().shivae_set_gemm_split(1 if a.arith == "split" else 0)
+        say("%s arithmetic: %s s" % (other, ", ".join("%.3f" % t for t in split_times)))
     per = torch.tensor([marks[i + 1] - marks[i] for i in range(steps)] + [dt] + split_times, device="cuda", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(per, op=dist.ReduceOp.MAX)
@@ -396,9 +407,13 @@ def main():
     if dom:
         ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12
         traffic, tsrc = pmc_traffic(a.config, B, T, dom["name"])
-        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+        split_kernel = dom["id"] == 24 or dom["id"] % 6 == 5
+        peak = PEAK_SPLIT_TFLOPS if split_kernel else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                 "kernel": dom["name"], "dtype": "f32",
+                "peak_is": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA products per fp32 product (fp32-equivalent flops)"
+                            if split_kernel else "fp32-input MFMA dense peak"),
                 "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                 "share_of_step": dom["ms"] / prof_ms,
                 "measured": "HIP events around every launch of one warm, untimed step"}
@@ -412,14 +427,15 @@ def main():
         if 20 <= p["id"] <= 23:
             e.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
         else:
-            e.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                     frac=rate / 1e12 / PEAK_F32_MFMA_TFLOPS)
+            pk = PEAK_SPLIT_TFLOPS if (p["id"] == 24 or (p["id"] < 18 and p["id"] % 6 == 5)) else PEAK_F32_MFMA_TFLOPS
+            e.update(bound="mfma", achieved=rate / 1e12, peak=pk, unit="TFLOP/s", frac=rate / 1e12 / pk)
         others.append(e)
     out = {"metric": "train sequence-timesteps/sec (ELBO fwd+bwd)", "value": value, "unit": "sequence-timesteps/s",
            "n_gpus": world, "steps": steps, "warmup": n_warm, "steps_requested": a.steps, "warmup_requested": a.warmup,
            "ms_per_step": ms_step, "ms_per_step_mean": dt / steps * 1e3, "ms_per_step_min": min(per) * 1e3,
            "ms_per_step_max": max(per) * 1e3, "statistic": "median of the timed steps (max over ranks per step)",
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "arithmetic": ARITH[a.arith],
            "config": {"workload": "%s: synthetic heterogeneous HMM, global batch %d, T=%d, D=%d (%d real/%d pos/%d bin/%d cat), "
                                   "h_dim=%d, z_dim=%d, K=%d, %d%% missing; fwd+bwd+allreduce+clip+Adam"
                                   % (a.config, B, T, len(tl), nr, npos, nb, len(cats), H, Z, K, int(miss * 100)),
@@ -431,12 +447,10 @@ def main():
            "n_elbo": float(lv), "roofline": roof, "roofline_other_kernels": others}
     if split_times:
         sm = sorted(split_times)[len(split_times) // 2]
-        out["split_bf16_mode"] = {
+        out["f32_mfma_mode" if other == "f32" else "split_bf16_mode"] = {
             "value": B * T / sm, "unit": "sequence-timesteps/s", "ms_per_step": sm * 1e3, "steps": len(split_times),
             "warmup": 1, "n_elbo": float(loss_s["n_elbo"].detach()) if dist is None else None,
-            "arithmetic": "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, fp32 "
-                          "accumulation (opt-in: shivae_set_gemm_split / SHIVAE_GEMM_SPLIT=1); same parity tests and "
-                          "tolerances as the fp32-MFMA mode"}
+            "arithmetic": ARITH[other]}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)

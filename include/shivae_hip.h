@@ -338,6 +338,8 @@ int shivae_scale_inverse(const float* x_dev, const uint8_t* mask_dev, int n, int
  * GEMM kernel variants (layout*6 + tile; work = flops), 18/19 the recurrent scan fwd/bwd (flops),
  * 20 the likelihood kernel, 21 the KL kernel (work = algorithmic bytes).  Not thread-safe. */
 int shivae_profile_start(void);
+/* 1 between shivae_profile_start and shivae_profile_stop (callers that capture HIP graphs must not capture then) */
+int shivae_profile_active(void);
 /* Diagnostics: while buf_dev is non-NULL every 128x128 GEMM workgroup writes 4 shader-clock stamps {start,
  * first K-tile staged, main loop done, epilogue done} to buf_dev[4*workgroup]. */
 int shivae_debug_gemm_stamps(unsigned long long* buf_dev);

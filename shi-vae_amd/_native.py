@@ -35,7 +35,7 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_init", "shivae_plan_se
            "shivae_allreduce_grads",
            "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
-           "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start",
+           "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start", "shivae_profile_active",
            "shivae_profile_stop", "shivae_debug_gemm_stamps"]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.shivae_scale_inverse.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     L.shivae_debug_gemm_stamps.argtypes = [vp]
     L.shivae_profile_start.argtypes = []
+    L.shivae_profile_active.argtypes = []
     L.shivae_profile_stop.argtypes = [C.POINTER(C.c_double), ci]
     _lib = L
     return L

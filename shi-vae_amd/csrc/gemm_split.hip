@@ -194,7 +194,6 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         const int t = q[(aidx && aok[i]) ? r : 0];
         abase[i] = (size_t)(aok[i] ? (aidx ? t : r) : 0) * p.lda;
     }
-    const gbl_f32_ptr Ag = (gbl_f32_ptr)g.A;
     auto loadA = [&](int kt, f32x4 (&v)[2]) {
         const int k = kt * 32 + 4 * akq;
         const bool kok = k < p.K;  // K % 4 == 0: a float4 is all-valid or all-invalid
@@ -325,6 +324,25 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
     __syncthreads();
 
     // ---- epilogue: the whole C tile is staged in LDS once, then every thread handles 16-B pieces of whole rows
+    //      (thread -> column quad c4, rows rw + 8 i).  What the pieces need from global memory -- the ReLU gate's
+    //      activations, the row list of a scattered store -- is requested for ALL 16 pieces before the staging, into
+    //      the registers the correction accumulators give back: one memory round trip per tile instead of one per round.
+    const int epi = p.epi;
+    const int c4 = tid & 63, col = n0 + c4 * 4, rw = tid >> 6;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] += cor[x][y];
+    f32x4 ax[16];
+    int crow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + rw + 8 * i;
+        const bool ok = row < Mrows;
+        crow[i] = row;
+        if (cidx) crow[i] = ((gbl_i32_ptr)cidx)[ok ? row : 0];
+        if (epi & EPI_MASK) ax[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.aux + (ok ? (size_t)row * p.ldaux + col : 0));
+    }
     float* cst = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -332,57 +350,38 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                cst[(wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SW_LDE + wn * 64 + y * 32 + li] =
-                    acc[x][y][r] + cor[x][y][r];
+                cst[(wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SW_LDE + wn * 64 + y * 32 + li] = acc[x][y][r];
     __syncthreads();
-    const int epi = p.epi;
-    const int c4 = tid & 63, col = n0 + c4 * 4, rw = tid >> 6;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi & EPI_BIAS) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) bias4[c] = *((gbl_f32_ptr)g.bias + col + c);
     }
-    constexpr int CH = 4;  // pieces in flight per thread (gate / old-C loads of a round are requested together)
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += CH) {
-        f32x4 v[CH], ax[CH], cold[CH];
-        bool ok[CH];
-        size_t off[CH];
+    for (int i = 0; i < 16; ++i) {
+        const int lr = rw + 8 * i, row = m0 + lr;
+        if (row >= Mrows) continue;
+        float* cp = g.C + (size_t)crow[i] * p.ldc + col;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(cst + lr * SW_LDE + c4 * 4);
+        float e[4] = {v.x, v.y, v.z, v.w};
+        if (epi & EPI_ATOMIC) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int lr = rw + 8 * (i0 + i), row = m0 + lr;
-            ok[i] = row < Mrows;
-            const int crow = cidx ? ((gbl_i32_ptr)cidx)[ok[i] ? row : 0] : row;
-            off[i] = ok[i] ? (size_t)crow * p.ldc + col : 0;
-            v[i] = *reinterpret_cast<const f32x4*>(cst + lr * SW_LDE + c4 * 4);
-            if (epi & EPI_MASK) ax[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.aux + (ok[i] ? (size_t)row * p.ldaux + col : 0));
-            if (epi & EPI_ADDC) cold[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.C + off[i]);
+            for (int c = 0; c < 4; ++c) sw_atomic_add(cp + c, e[c]);
+            continue;
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (!ok[i]) continue;
-            float* cp = g.C + off[i];
-            float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            if (epi & EPI_ATOMIC) {
+        for (int c = 0; c < 4; ++c) e[c] += bias4[c];
+        if (epi & EPI_RELU) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) sw_atomic_add(cp + c, e[c]);
-                continue;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] += bias4[c];
-            if (epi & EPI_ADDC) { e[0] += cold[i].x; e[1] += cold[i].y; e[2] += cold[i].z; e[3] += cold[i].w; }
-            if (epi & EPI_RELU) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) e[c] = fmaxf(e[c], 0.f);
-            }
-            if (epi & EPI_MASK) {
-                e[0] = ax[i].x > 0.f ? e[0] : 0.f; e[1] = ax[i].y > 0.f ? e[1] : 0.f;
-                e[2] = ax[i].z > 0.f ? e[2] : 0.f; e[3] = ax[i].w > 0.f ? e[3] : 0.f;
-            }
-            sw_gstore4(cp, e[0], e[1], e[2], e[3]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cs4[c] += e[c];
+            for (int c = 0; c < 4; ++c) e[c] = fmaxf(e[c], 0.f);
         }
+        if (epi & EPI_MASK) {
+            e[0] = ax[i].x > 0.f ? e[0] : 0.f; e[1] = ax[i].y > 0.f ? e[1] : 0.f;
+            e[2] = ax[i].z > 0.f ? e[2] : 0.f; e[3] = ax[i].w > 0.f ? e[3] : 0.f;
+        }
+        sw_gstore4(cp, e[0], e[1], e[2], e[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cs4[c] += e[c];
     }
     if (epi & EPI_COLSUM) {
         // the 8 waves hold partial sums of the same 256 columns: meet in LDS, one atomic per column and tile
@@ -403,7 +402,7 @@ static bool sw_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q)
 // Shapes this kernel takes (everything else stays on gemm.hip's kernels)
 bool split_nt_fits(const GemmDesc& d) {
     return d.layout == GEMM_NT && d.N >= SW_BN && d.N % SW_BN == 0 && d.K % 4 == 0 && d.K >= 32 && d.lda % 4 == 0 &&
-           d.ldc % 4 == 0 && (!(d.epi & EPI_MASK) || d.ldaux % 4 == 0) && !(d.epi & EPI_SOFTPLUS) && !d.unaligned &&
+           d.ldc % 4 == 0 && (!(d.epi & EPI_MASK) || d.ldaux % 4 == 0) && !(d.epi & (EPI_SOFTPLUS | EPI_ADDC)) && !d.unaligned &&
            !(d.ragged & RAG_BIDX) && d.M > 64;
 }
 

@@ -1410,6 +1410,8 @@ int shivae_gemm_nt_presplit(int M, int N, int K, const float* A, int lda, const 
     return launch_gemm_split_nt(d, nullptr, 1, g, static_cast<hipStream_t>(stream));
 }
 
+int shivae_profile_active(void) { return g_prof_on ? 1 : 0; }
+
 int shivae_profile_start(void) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();

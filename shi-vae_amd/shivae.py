@@ -85,6 +85,13 @@ class ShiVAE(nn.Module):
         # run.  Opt-in, because the caller then HAS to call allreduce_grads() (bench.py and Trainer do).
         self.overlap_allreduce = False
         self.bucket_floats = int(float(os.environ.get("SHIVAE_BUCKET_MB", "128")) * (1 << 18))
+        # Small models are launch-bound (cfg1 / cfg2: ~125 launches for a 2-3 ms step): a step whose shapes and scalars
+        # repeat is captured into a HIP graph on its second occurrence and replayed afterwards.  None = automatic
+        # (single micro-batch, single decoder row chunk, at most `graph_max_rows` (t,b) rows), False = never.
+        self.use_graphs = None if os.environ.get("SHIVAE_GRAPHS", "auto") == "auto" else os.environ["SHIVAE_GRAPHS"] not in ("0", "off")
+        self.graph_max_rows = 1 << 16
+        self._graphs = {}
+        self._graph_seen = set()
         self._pending_reduce = []
         self._pending_noise = None
         self._plans = {}
@@ -203,6 +210,7 @@ class ShiVAE(nn.Module):
         self._hook = torch.zeros(1, device=dev, requires_grad=True)
         self.device = dev.type
         self._plans, self._active, self._workspace = {}, None, None
+        self._graphs, self._graph_seen = {}, set()
 
     @property
     def flat_params(self):
@@ -354,6 +362,10 @@ class ShiVAE(nn.Module):
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
         bm = self.micro_batches(T, B)[0]
         self._grow_chunk(T, min(bm, B))
+        if self._graph_eligible(T, B, bm, collect):
+            done = self._step_graphed(x, mask, u, eps, float(beta), float(temp), inv_batch, flags)
+            if done is not None:
+                return done, {}
         outs = {w: [] for w in (collect or [])}
         persum = []
         L = N.lib()
@@ -389,6 +401,56 @@ class ShiVAE(nn.Module):
         outs = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
         self._last = dict(u=u, eps=eps, persum=torch.cat(persum) if persum else None)
         return losses, outs
+
+    # ------------------------------------------------------------------ captured steps (small, launch-bound models)
+    def _graph_eligible(self, T, B, bm, collect):
+        if self.use_graphs is False or collect or bm < B or T * B > self.graph_max_rows:
+            return False
+        if self._dp_backend() is not None and self.overlap_allreduce:
+            return False  # (the overlapped all-reduce interleaves host-side collectives with the phases)
+        if N.lib().shivae_profile_active():
+            return False  # (the per-launch HIP events of the profiler cannot be recorded into a graph)
+        plan = self._plans.get((T, B))
+        return plan is None or plan.chunk_rows >= T * B
+
+    def _step_graphed(self, x, mask, u, eps, beta, temp, inv_batch, flags):
+        """The step through a HIP graph: the first call with a given (shape, scalars) runs eagerly (it binds the plan,
+        allocates the workspace and, for training steps, lets the plan measure its observed fraction); the second
+        captures shivae_elbo_step + the per-sequence sums on static buffers; later ones copy the inputs in and replay.
+        -> losses tensor, or None to make the caller take the eager path."""
+        T, B, _ = x.shape
+        key = (T, B, flags, beta, temp, inv_batch)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if key not in self._graph_seen:
+                self._graph_seen.add(key)
+                return None
+            if len(self._graphs) >= 8:  # (schedules move beta / temp every epoch: keep the cache small)
+                self._graphs.pop(next(iter(self._graphs)))
+            dev = self._flat.device
+            plan = self._activate(T, B)
+            ent = dict(x=torch.empty_like(x), m=torch.empty(mask.shape, dtype=torch.uint8, device=dev), u=torch.empty_like(u),
+                       e=torch.empty_like(eps), losses=torch.zeros(16, device=dev), ps=torch.empty(B, 6, device=dev),
+                       plan=plan, graph=torch.cuda.CUDAGraph())
+            L = N.lib()
+            torch.cuda.synchronize()
+            try:
+                with torch.cuda.graph(ent["graph"]):
+                    ent["losses"].zero_()
+                    N.check(L.shivae_elbo_step(plan.h, N.ptr(ent["x"]), N.ptr(ent["m"]), N.ptr(ent["u"]), N.ptr(ent["e"]), beta,
+                                               temp, inv_batch, flags, N.ptr(ent["losses"]), N.stream()))
+                    N.check(L.shivae_get_persum(plan.h, N.ptr(ent["ps"]), N.stream()))
+            except Exception:
+                self.use_graphs = False  # (capture not possible here: stay on the eager path for good)
+                return None
+            self._graphs[key] = ent
+        if self._active is not ent["plan"]:  # another shape ran in between: the workspace has to be this plan's again
+            self._graphs.pop(key)
+            return None
+        ent["x"].copy_(x); ent["m"].copy_(mask); ent["u"].copy_(u); ent["e"].copy_(eps)
+        ent["graph"].replay()
+        self._last = dict(u=u, eps=eps, persum=ent["ps"].clone())
+        return ent["losses"].clone()
 
     def forward(self, x, mask, beta=1., temp=3, inv_batch=None):
         """base_missvae.py:144-164: dict of the 9 loss scalars (K*M == 1, so the ``repeat`` is a no-op).

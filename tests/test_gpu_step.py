@@ -82,6 +82,37 @@ def test_losses_and_gradients_match_reference(name):
 
 
 @pytest.mark.parametrize("name", _golden.CASES)
+def test_captured_step_matches_reference(name):
+    """Small models replay their step from a HIP graph from the third call with the same shapes and scalars on
+    (ShiVAE._step_graphed): first call eager, second captures and replays, third replays.  Every one of them must give
+    the reference's losses and gradients."""
+    g, cfg, sd = _golden.load(name)
+    m = _model(cfg, sd)
+    m.train()
+    m.use_graphs = True
+    x, mask = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    for call in range(3):
+        m.zero_grad()
+        m.set_noise(g["u"], g["eps"])
+        loss = m(x, mask, beta=cfg["beta"], temp=cfg["temp"])
+        for k in shivae_amd.LOSS_KEYS:
+            np.testing.assert_allclose(float(loss[k]), g["loss/" + k], rtol=LOSS_RTOL, atol=1e-5, err_msg="%s call %d" % (k, call))
+        loss["n_elbo"].backward()
+        bad = _golden.bad_grads(_grads(m), {k: g["grad/" + k] for k, _ in m.named_parameters()})
+        assert not bad, (call, bad[:8])
+        ps = m._last["persum"].cpu().numpy()
+        np.testing.assert_allclose(ps[:, 4], g["klz_b"], rtol=1e-4, atol=1e-4)
+    assert len(m._graphs) == 1, "the step was not captured"
+    # other scalars -> another graph; the first one stays valid
+    m.zero_grad(); m.set_noise(g["u"], g["eps"])
+    l2 = m(x, mask, beta=0.5 * cfg["beta"] + 0.1, temp=cfg["temp"])
+    m.zero_grad(); m.set_noise(g["u"], g["eps"])
+    l3 = m(x, mask, beta=cfg["beta"], temp=cfg["temp"])
+    np.testing.assert_allclose(float(l3["n_elbo"]), g["loss/n_elbo"], rtol=LOSS_RTOL, atol=1e-5)
+    assert abs(float(l2["n_elbo"]) - float(l3["n_elbo"])) > 0
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
 def test_fused_clip_adam_on_golden_gradients(name):
     """trainers.py:222-224 clip_grad_norm_(0.5) + Adam(lr=5e-3).step() on the reference's own gradients: the HIP
     optimiser alone (gradient buffer filled from the golden vectors), then compared with the reference's
