@@ -262,7 +262,7 @@ class ShiVAE(nn.Module):
         if self.chunk_rows or (T, B) in self._chunk_done:
             return
         self._chunk_done.add((T, B))
-        budget = self._budget()
+        budget = self._budget() - getattr(self, "_slice_reserve", 0)
         p0 = self._make_plan(T, B)
         rc0, ws0 = p0.chunk_rows, p0.workspace_bytes
         if rc0 >= T * B or ws0 >= budget:
@@ -285,8 +285,10 @@ class ShiVAE(nn.Module):
         """Largest per-call batch whose workspace fits the budget (callers' B is split into these)."""
         budget = self._budget()
         bm = B
+        # a split batch also needs contiguous copies of each micro-batch's x, mask, u, eps slices
+        slices = lambda b: 0 if b >= B else T * b * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
         while True:
-            ws = self._make_plan(T, bm).workspace_bytes
+            ws = self._make_plan(T, bm).workspace_bytes + slices(bm)
             if ws <= budget or bm <= 16:
                 return bm
             self._plans.pop((T, bm), None)
@@ -361,6 +363,7 @@ class ShiVAE(nn.Module):
         losses = torch.zeros(16, dtype=torch.float32, device=dev)
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
         bm = self.micro_batches(T, B)[0]
+        self._slice_reserve = 0 if bm >= B else T * bm * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
         self._grow_chunk(T, min(bm, B))
         if self._graph_eligible(T, B, bm, collect):
             done = self._step_graphed(x, mask, u, eps, float(beta), float(temp), inv_batch, flags)
