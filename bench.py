@@ -3,8 +3,10 @@
 
   python bench.py --gpus N --steps K --warmup W [--config cfg3]
 
-One process per GPU (torch.distributed over RCCL when N > 1, launched by torch.distributed.run);
-rank 0 prints ONE JSON line.  Metric: train sequence-timesteps/s = B_global*T / median step time.
+One process per GPU (torch.distributed over RCCL when N > 1).  Run under torch.distributed.run it is one rank;
+run plainly with --gpus N > 1 it starts the N ranks itself as a child process (launch_ranks) -- and refuses, with a
+non-zero exit and no result line, a rank count it cannot run (more ranks than devices; --gpus != WORLD_SIZE).
+Rank 0 prints ONE JSON line.  Metric: train sequence-timesteps/s = B_global*T / median step time.
 Default workload = BASELINE.json configs[2] ("cfg3"): synthetic heterogeneous HMM, global batch 8192,
 T=1000, D=256 mixed types (64 real/64 pos/64 bin/64 cat, C=4), h_dim=256, z_dim=64, K=16, 30 % missing;
 N GPUs shard the SAME global batch by sequence (strong scaling, configs[3]): rank r generates exactly rows
@@ -15,7 +17,13 @@ clamped to what fits SHIVAE_BENCH_BUDGET_S (default 480 s, counted from process 
 3 timed steps).  The JSON line reports the counts that actually ran (`steps`, `warmup`) next to the requested
 ones.  Order: set-up -> bounded CPU baseline (rank 0, N=1) -> cold warm-up step -> one warm step under the
 library's per-launch HIP events (the roofline figures; never inside the timed region) -> remaining warm-ups ->
-timed steps (per-step host clock after a device sync; max over ranks; the median is reported)."""
+timed steps (per-step host clock after a device sync; max over ranks; the median is reported) -> one step of the
+OTHER arithmetic of the decoder GEMMs when >= 8 headline steps fit beside it.
+
+Arithmetic (--arith): both compute fp32 products of fp32 data into fp32.  `split` (default; DESIGN.md s.4 "Split
+mode") forms every product from six bf16 MFMA products of an exact 3-way bf16 split, with error at or below the
+fp32-input MFMA's on adversarial operands (tests/test_gpu_split_mode.py); `f32` is the fp32-input MFMA itself.  The
+line names the arithmetic of `value` and carries the other one as `f32_mfma_mode` / `split_bf16_mode`."""
 import argparse
 import json
 import math
@@ -260,6 +268,7 @@ def main():
     blk = max(1, math.gcd(512, B // 16)) if B % 16 == 0 else B
     assert (rank * Bl) % blk == 0, "shard of %d sequences does not start on a block of %d" % (Bl, blk)
     x, mask = synth_batch(tl, T, Bl, miss=miss, seed=1234, device="cuda", chunk=blk, seq0=rank * Bl)
+    n_missing = sum(int(torch.count_nonzero(mask[t0:t0 + 8])) for t0 in range(0, T, 8))  # (in slabs: no full-size temporaries)
     torch.manual_seed(100 + rank)  # per-rank noise stream (device generator)
     micro = model.micro_batches(T, Bl)
     torch.cuda.synchronize()
@@ -442,7 +451,7 @@ def main():
                       "global_batch": B, "seq_len": T, "parallelism": "dp%d" % world,
                       "micro_batch": micro[0], "micro_batches_per_rank": len(micro),
                       "params": int(sum(p.numel() for p in model.parameters())),
-                      "missing_frac": round(float(mask.float().mean()), 4)},
+                      "missing_frac": round(n_missing / mask.numel(), 4)},
            "wall_s": time.perf_counter() - T_PROC0, "budget_s": a.budget,
            "n_elbo": float(lv), "roofline": roof, "roofline_other_kernels": others}
     if split_times:

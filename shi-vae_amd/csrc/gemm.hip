@@ -69,10 +69,16 @@ __device__ __forceinline__ void gatomic_add(float* p, float v) {
 // LDS images of a split tile (bf16, built when the fp32 registers are parked in LDS):
 //   K-contiguous operand  : [rows][104] halves = hi[32] | mid[32] | lo[32] | pad[8]; a lane's fragment of one plane
 //                           (8 consecutive k) is one ds_read_b128; 208-B rows are conflict-free for them
-//   row-contiguous operand: [plane][16 k-pairs][rows] dwords, a dword = the bf16 pair (k, k+1) of one row; a
-//                           fragment is 4 ds_read_b32 (consecutive rows -> consecutive banks)
+//   row-contiguous operand: [plane][8 k-quads][row & 3][row >> 2 (+8 pad)][2 dwords]: the four k of a k-quad of one
+//                           row are 8 contiguous bytes, so a fragment (8 k) is 2 ds_read_b64 (256 B/clk; the
+//                           first form, [k-pair][rows] dwords and 4 ds_read_b32 at 128 B/clk, made the TN / NN
+//                           kernels LDS-bound).  A thread holds 4 consecutive k of 4 consecutive rows and stores
+//                           one 8-B piece per row: lanes = consecutive row quads = contiguous LDS.  The padded
+//                           stride of the (row & 3) blocks puts the four blocks a read touches on disjoint banks.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int SPLIT_RS = 104;  // halves per row of the K-contiguous split image
+__host__ __device__ constexpr int split_qs(int rows) { return rows / 4 + 8; }        // row-quad stride of a (row & 3) block
+__host__ __device__ constexpr int split_rc_plane(int rows) { return 64 * split_qs(rows); }  // dwords per plane
 
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // {bf16 trunc(a), bf16 trunc(b)} as one dword
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302);
@@ -168,7 +174,7 @@ struct TileLoader {
     // split mode: park the tile as three bf16 planes (layouts above)
     __device__ __forceinline__ void store_split(float* lds, int tid) const {
         unsigned* l32 = reinterpret_cast<unsigned*>(lds);
-        if (KC) {
+        if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int r = prow(i, tid), k = pk(i, tid);
@@ -181,23 +187,22 @@ struct TileLoader {
                 *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
             }
         } else {
-            static_assert(KC || NV % 2 == 0, "row-contiguous split tiles pack k pairs");
+            static_assert(KC || NV == 4, "row-contiguous split tiles: a thread holds one k-quad of four rows");
+            const int q = prow(0, tid) >> 2, kq = pk(0, tid) >> 2;
+            float hh[4][4], mm[4][4], ll[4][4];  // [k][row]
 #pragma unroll
-            for (int i = 0; i + 1 < NV; i += 2) {
-                const int r = prow(i, tid), k = pk(i, tid);  // k even; piece i+1 is k+1 of the same rows
-                const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, o[4] = {v[i + 1].x, v[i + 1].y, v[i + 1].z, v[i + 1].w};
-                unsigned ph[4], pm[4], pl[4];
+            for (int i = 0; i < 4; ++i) {
+                const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float h0, m0, l0, h1, m1, l1;
-                    split3(e[c], h0, m0, l0);
-                    split3(o[c], h1, m1, l1);
-                    ph[c] = pack_hi16(h0, h1); pm[c] = pack_hi16(m0, m1); pl[c] = pack_hi16(l0, l1);
-                }
-                unsigned* d = l32 + (k / 2) * ROWS + r;
-                *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-                *reinterpret_cast<uint4*>(d + 16 * ROWS) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-                *reinterpret_cast<uint4*>(d + 32 * ROWS) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                for (int c = 0; c < 4; ++c) split3(e[c], hh[i][c], mm[i][c], ll[i][c]);
+            }
+            constexpr int QS = split_qs(ROWS), PL = split_rc_plane(ROWS);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // row 4 q + c: its k-quad as two bf16 pairs
+                unsigned* d = l32 + ((kq * 4 + c) * QS + q) * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hh[0][c], hh[1][c]), pack_hi16(hh[2][c], hh[3][c]));
+                *reinterpret_cast<uint2*>(d + PL) = make_uint2(pack_hi16(mm[0][c], mm[1][c]), pack_hi16(mm[2][c], mm[3][c]));
+                *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(pack_hi16(ll[0][c], ll[1][c]), pack_hi16(ll[2][c], ll[3][c]));
             }
         }
     }
@@ -210,8 +215,10 @@ __device__ __forceinline__ bf16x8 read_frag_split(const float* lds, int row, int
     uint4 u;
     if (KC) u = *reinterpret_cast<const uint4*>(l32 + (row * SPLIT_RS + p * 32 + 16 * s + 8 * h) / 2);
     else {
-        const unsigned* q = l32 + (p * 16 + 8 * s + 4 * h) * ROWS + row;
-        u = make_uint4(q[0], q[ROWS], q[2 * ROWS], q[3 * ROWS]);
+        constexpr int QS = split_qs(ROWS), PL = split_rc_plane(ROWS);
+        const unsigned* q = l32 + p * PL + (((4 * s + 2 * h) * 4 + (row & 3)) * QS + (row >> 2)) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + 4 * QS * 2);
+        u = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
     return __builtin_bit_cast(bf16x8, u);
 }
@@ -356,8 +363,8 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_kernel(GemmParams p) {
     static_assert(!SPLIT || !DMA, "split mode converts in registers");
     static_assert(WM * WN <= 8, "at most 8 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-    constexpr int LDS_A = SPLIT ? (A_KC ? BM * SPLIT_RS / 2 : 48 * BM) : (A_KC ? BM * (DMA ? 32 : 36) : 32 * BM);
-    constexpr int LDS_B = SPLIT ? (B_KC ? BN * SPLIT_RS / 2 : 48 * BN) : (B_KC ? BN * (DMA ? 32 : 36) : 32 * BN);
+    constexpr int LDS_A = SPLIT ? (A_KC ? BM * SPLIT_RS / 2 : 3 * split_rc_plane(BM)) : (A_KC ? BM * (DMA ? 32 : 36) : 32 * BM);
+    constexpr int LDS_B = SPLIT ? (B_KC ? BN * SPLIT_RS / 2 : 3 * split_rc_plane(BN)) : (B_KC ? BN * (DMA ? 32 : 36) : 32 * BN);
     constexpr int STAGE = LDS_A + LDS_B;
     // (the epilogue stages 32-row bands of the C tile in the same array: keep room for four of them)
     constexpr int LDS_FLOATS = (DB ? 2 : 1) * STAGE > 4 * 32 * (BN + 4) || !DMA ? (DB ? 2 : 1) * STAGE : 4 * 32 * (BN + 4);
@@ -824,7 +831,9 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
         if (g_gemm_split > 0) {
             static const int st = [] { const char* f = getenv("SHIVAE_SPLIT_TILE"); return f ? atoi(f) : 0; }();
             if (st == 1) return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2, 2, false, false, true>(p, ngroups, stream);  // 4 waves of 64x64
-            if (st == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 2, true, false, true>(p, ngroups, stream);   // two LDS stages, 1 WG/CU
+            if constexpr (A_KC && B_KC) {
+                if (st == 2) return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 2, true, false, true>(p, ngroups, stream);   // two LDS stages, 1 WG/CU
+            }
             if constexpr (A_KC) {
                 // 64 x 256 tiles for N a multiple of 256 (activation operand fetched once per 256 output columns):
                 // measured 7 % slower than 128 x 128 in the training step (144.7 against 155.9 TFLOP/s), kept for A/B runs
@@ -834,7 +843,7 @@ static int launch_tiles(const GemmParams& p, int ngroups, hipStream_t stream) {
             // row-contiguous fragments need more registers and spilled there (64-80 B per lane, TN 150 -> 90 TFLOP/s),
             // so they run 4 waves of 64 x 64 at 256 registers, still two workgroups per CU
             if constexpr (!B_KC) return launch_cfg<A_KC, B_KC, VEC, 2, 2, 2, 2, 2, false, false, true>(p, ngroups, stream);
-            return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false, false, true>(p, ngroups, stream);
+            else return launch_cfg<A_KC, B_KC, VEC, 4, 2, 1, 2, 4, false, false, true>(p, ngroups, stream);
         }
         // LDS-DMA staging.  TN masks the tail of the last K-tile, so any K and ragged K go; K-contiguous operands
         // need whole K-tiles, and dense rows (no row lists on this path for them).  Measured in the training step

@@ -382,7 +382,7 @@ static int build_tables(shivae_plan* p) {
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     const float* embc = p->wsf("embc");
     std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, dl0, dl0r, wl1, dl1, wl2, dl2, wh0, dh0;
-    std::vector<GemmGroup> fl0i, fl1i, fl2i, fh0i, dl1i, dl2i, dh0i;  // B = pre-split weight image
+    std::vector<GemmGroup> fl0i, fl1i, fl2i, fh0i, dl0i, dl1i, dl2i, dh0i;  // B = pre-split weight image
     auto IMG = [&](const char* name, size_t idx, int N, int K) {
         return reinterpret_cast<const float*>(p->ws + p->ws_off.at(name) + idx * presplit_bytes(N, K));
     };
@@ -428,6 +428,12 @@ static int build_tables(shivae_plan* p) {
         fl1.push_back(G(a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr, nullptr));
         fl2.push_back(G(a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr, nullptr));
         twin(fl0i, fl0.back(), IMG("wi_f0", d, 2 * H, p->E));
+        // compact layer-0 input gradient against attribute d's K range of the transposed stack's image (rows = E,
+        // K-tiles d*2H/32 ...: the image is K-tile major, so a K range is a contiguous slab)
+        if ((2 * H) % 32 == 0)
+            twin(dl0i, dl0.back(), reinterpret_cast<const float*>(
+                                       reinterpret_cast<const char*>(IMG("wi_t0", 0, p->E, D * 2 * H)) +
+                                       (size_t)d * (2 * H / 32) * 3 * p->E * 64));
         twin(fl1i, fl1.back(), IMG("wi_f2", d, H, 2 * H));
         twin(fl2i, fl2.back(), IMG("wi_f4", d, H, H));
         wl2.push_back(G(da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr, nullptr));
@@ -479,6 +485,7 @@ static int build_tables(shivae_plan* p) {
     SV_TRY(make_table(p, wh0, p->b_h0_w, bc)); SV_TRY(make_table(p, dh0, p->b_h0_d, bc));
     SV_TRY(upload(p, fl0i, &p->f_l0.dev_img)); SV_TRY(upload(p, fl1i, &p->f_l1.dev_img));
     SV_TRY(upload(p, fl2i, &p->f_l2.dev_img)); SV_TRY(upload(p, fh0i, &p->f_h0.dev_img));
+    SV_TRY(upload(p, dl0i, &p->b_l0_d.dev_img));
     SV_TRY(upload(p, dl1i, &p->b_l1_d.dev_img)); SV_TRY(upload(p, dl2i, &p->b_l2_d.dev_img));
     SV_TRY(upload(p, dh0i, &p->b_h0_d.dev_img));
     for (auto& kv : fo) SV_TRY(make_table(p, kv.second, p->f_out[kv.first], ko[kv.first]));
@@ -581,9 +588,9 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
 // rag_cnt: pinned host copy of the chunk's row counts while profiling (else null); see prof_ragged
 static const int* g_chunk_cnt_host = nullptr;
 static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int epi, const GroupTable& t,
-                 hipStream_t s, int ragged = 0, bool shared_c = false) {
+                 hipStream_t s, int ragged = 0, bool shared_c = false, int nimg = 0) {
     if (t.n == 0) return SHIVAE_OK;
-    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned, ragged};
+    GemmDesc d{layout, M, N, K, lda, ldb, ldc, ldaux, epi, 1, t.unaligned, t.c_aligned, ragged, nimg};
     // (shared_c: the groups add into the same C, so the adds stay atomic even with one workgroup per tile)
     if (epi == EPI_ATOMIC && !shared_c) {
         d.splitk = splitk_for(M, N, K, t.n);
@@ -881,7 +888,13 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         if (cd) {
             const int nm = p->l0_nmain;
             SV_CHECK_HIP(hipMemsetAsync(dembc, 0, (size_t)rc * E4 * sizeof(float), s));
-            SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
+            // (split mode: as an NT launch against the attribute's K range of the transposed stack's weight image)
+            static const bool l0d_img = [] { const char* f = getenv("SHIVAE_L0D_IMG"); return !f || atoi(f) != 0; }();
+            GemmDesc probe{NT, rc, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, 1, 0, 1, RAG_CNT | RAG_CIDX, E};
+            if (split && l0d_img && p->b_l0_d.dev_img && split_nt_fits(probe))
+                SV_TRY(gemmg(NT, rc, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true, E));
+            else
+                SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
             if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_dr, s, RAG_CNT | RAG_CIDX, true));
         } else {
             SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s,

@@ -262,7 +262,7 @@ class ShiVAE(nn.Module):
         if self.chunk_rows or (T, B) in self._chunk_done:
             return
         self._chunk_done.add((T, B))
-        budget = self._budget() - getattr(self, "_slice_reserve", 0)
+        budget = self._budget(getattr(self, "_slice_reserve", 0))
         p0 = self._make_plan(T, B)
         rc0, ws0 = p0.chunk_rows, p0.workspace_bytes
         if rc0 >= T * B or ws0 >= budget:
@@ -274,21 +274,27 @@ class ShiVAE(nn.Module):
         self._make_plan(T, B, chunk_rows=max(rc, rc0))
         self._active = None
 
-    def _budget(self):
+    def _budget(self, reserve=0):
+        """Bytes the workspace may take: what is free now plus what the current workspace holds, minus head-room --
+        15 %, or `reserve` (the contiguous x / mask / u / eps slices of a split batch) + 4 GB if that is more."""
         if self.workspace_limit_bytes:
             return self.workspace_limit_bytes
-        free, _ = torch.cuda.mem_get_info(self._flat.device)
+        dev = self._flat.device
+        free, _ = torch.cuda.mem_get_info(dev)
+        # (+ what torch's caching allocator holds without using it: the driver does not count that as free)
+        cached = max(0, torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
         held = self._workspace.numel() if self._workspace is not None else 0
-        return int((free + held) * 0.85)
+        total = free + cached + held
+        return int(total - max(0.15 * total, reserve + 4e9))
 
     def micro_batch(self, T, B):
         """Largest per-call batch whose workspace fits the budget (callers' B is split into these)."""
-        budget = self._budget()
         bm = B
         # a split batch also needs contiguous copies of each micro-batch's x, mask, u, eps slices
         slices = lambda b: 0 if b >= B else T * b * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
         while True:
-            ws = self._make_plan(T, bm).workspace_bytes + slices(bm)
+            budget = self._budget(slices(bm))
+            ws = self._make_plan(T, bm).workspace_bytes
             if ws <= budget or bm <= 16:
                 return bm
             self._plans.pop((T, bm), None)
@@ -372,9 +378,11 @@ class ShiVAE(nn.Module):
         outs = {w: [] for w in (collect or [])}
         persum = []
         L = N.lib()
+        xs = ms = us = es = None
         for b0 in range(0, B, bm):
             b1 = min(B, b0 + bm)
             plan = self._activate(T, b1 - b0)
+            xs = ms = us = es = None  # (the previous micro-batch's slices go back to the allocator BEFORE the next ones are cut)
             if b0 == 0 and b1 == B:
                 xs, ms, us, es = x.contiguous(), mask.contiguous(), u, eps
             else:
@@ -504,10 +512,19 @@ class ShiVAE(nn.Module):
                 off += C - 1
         return likes
 
-    def _params_from_likes(self, likes):
+    def _params_from_likes(self, likes, like_ref=None):
+        """Raw head outputs [T,B,P] from the likelihood objects; attributes absent from `likes` (heter_nll on a subset)
+        get zeros shaped like `like_ref`'s batch dimensions."""
         cols = []
         for t in self.types_list:
-            lk, ty = likes[t['name']], t['type']
+            ty = t['type']
+            if t['name'] not in likes:
+                ref = next(iter(likes.values())) if like_ref is None else like_ref
+                shp = tuple((ref.loc if hasattr(ref, 'loc') else ref.logits).shape[:-1])
+                n = (2 if self.learn_std else 1) if ty in ('real', 'pos') else (1 if ty == 'bin' else int(t['dim']) - 1)
+                cols.append(torch.zeros(shp + (n,), device=self._flat.device))
+                continue
+            lk = likes[t['name']]
             if ty in ('real', 'pos'):
                 cols.append(lk.loc)
                 if self.learn_std:
@@ -536,8 +553,6 @@ class ShiVAE(nn.Module):
     @torch.no_grad()
     def heter_nll(self, x, mask, likes, types_list=None, eval_obs=False):
         """base_missvae.py:233-285 via the HIP likelihood kernel: dict nll_<type> -> [B]."""
-        if types_list is not None and [t['name'] for t in types_list] != [t['name'] for t in self.types_list]:
-            raise NotImplementedError("heter_nll on a subset of the attributes")
         self._require_gpu()
         dev = self._flat.device
         x = torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
@@ -545,6 +560,18 @@ class ShiVAE(nn.Module):
         mask = (mask != 0) if mask.dtype != torch.bool else mask
         if eval_obs:
             mask = ~mask  # :278-279 evaluate on the missing entries instead
+        if types_list is not None:
+            # a subset of the attributes (:254 loops over the list it is given): the others count as missing everywhere
+            names = {t['name'] for t in types_list}
+            unknown = names - {t['name'] for t in self.types_list}
+            if unknown:
+                raise KeyError("heter_nll: attributes %s are not in the model's types_list" % sorted(unknown))
+            if len(names) < len(self.types_list):
+                mask = mask.clone()
+                for t, lo in zip(self.types_list, self.transform_idx):
+                    if t['name'] not in names:
+                        mask[..., lo:lo + int(t['dim'])] = True
+                likes = {k: v for k, v in likes.items() if k in names}
         T, B, _ = x.shape
         P = self._params_from_likes(likes)
         rowloss = torch.zeros(T * B, 6, device=dev)

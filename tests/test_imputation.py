@@ -86,3 +86,28 @@ def test_gpu_reconstruction_end_to_end():
     # MC mean of the Normal attributes stays within 6 sigma/sqrt(100) of the likelihood mean
     lik = likes[tl[0]["name"]]
     assert ((xhat[..., :1] - lik.loc).abs() <= 0.6 * lik.scale + 1e-6).all()
+
+
+@pytest.mark.gpu
+def test_heter_nll_on_attribute_subsets():
+    """base_missvae.py:233-252 takes the list of attributes to evaluate: the terms of two complementary subsets add up
+    to the terms of the whole list, per type and per sequence; unknown attributes are refused."""
+    import _golden
+    import shivae_amd
+    g, cfg, sd = _golden.load("tiny_all")
+    m = shivae_amd.ShiVAE(cfg["H"], cfg["Z"], cfg["K"], 1, types_list=cfg["types_list"], learn_std=cfg["learn_std"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    x, mask = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    m.set_noise(g["u"], g["eps"])
+    _, _, _, likes = m.feed2model(x, cfg["temp"])
+    full = m.heter_nll(x, mask, likes)
+    tl = m.types_list
+    a, b = tl[::2], tl[1::2]
+    na, nb = m.heter_nll(x, mask, likes, types_list=a), m.heter_nll(x, mask, {t["name"]: likes[t["name"]] for t in b}, types_list=b)
+    for k in full:
+        np.testing.assert_allclose((na[k] + nb[k]).cpu().numpy(), full[k].cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(full[k].cpu().numpy(), g["nll_b/" + k], rtol=1e-4, atol=2e-4, err_msg=k)
+    assert float(sum(v.abs().sum() for v in na.values())) > 0 and float(sum(v.abs().sum() for v in nb.values())) > 0
+    with pytest.raises(KeyError):
+        m.heter_nll(x, mask, likes, types_list=[dict(name="no_such_var", type="real", dim="1", nclass="", index="0")])
