@@ -26,6 +26,7 @@
 // lanes of a ds_read_b128 lane group hit 16 distinct 4-bank slots.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -40,6 +41,13 @@ typedef const __attribute__((address_space(1))) f32x4* gbl_f32x4_ptr;
 typedef const __attribute__((address_space(1))) int* gbl_i32_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+#ifndef SW_DBG
+#define SW_DBG 0  // diagnostic builds (tools/build_variant.sh): 4 no MFMA, 8 no fragment reads.  There is NO switch
+                  // that drops the DMAs or the activation loads: the loop's hand-counted vmcnt waits count on them; with
+                  // fewer operations in flight `vmcnt(8)` stops waiting, the registers of the consumed activation set
+                  // are handed out as address temporaries, and the late load lands on an address (GPU fault, seen once)
+#endif
 
 constexpr int SW_BM = 128, SW_BN = 256, SW_NT = 512;
 constexpr int SW_A_BYTES = 3 * SW_BM * 64;
@@ -136,6 +144,40 @@ __device__ __forceinline__ void sw_wait_loads(f32x4 (&v)[2]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N) : "memory");
 }
 
+// 16-B LDS read / waits the compiler does not track, same reason (see the K loop).  OFF: the instruction's offset field
+template <int OFF>
+__device__ __forceinline__ bf16x8 sw_ds_read16(int addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    bf16x8 v;
+#if SW_DBG & 8
+    asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr) : "memory");
+#else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+#endif
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void sw_wait_lds(bf16x8 (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sw_wait_lds(bf16x8 (&a)[3], bf16x8 (&b)[2][3]) {
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]),
+                   "+v"(b[1][1]), "+v"(b[1][2])
+                 : "n"(N)
+                 : "memory");
+}
+// before the barrier: at most the 2 youngest vector-memory operations (the activation loads) and no LDS operation
+// outstanding
+__device__ __forceinline__ void sw_wait_all_lds(bf16x8 (&a)[2][3], bf16x8 (&b)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(b[0][0]),
+                   "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])
+                 :
+                 : "memory");
+}
+
 __device__ __forceinline__ void sw_gstore4(float* p, float a, float b, float c, float d) {
     f32x4 t;
     t.x = a; t.y = b; t.z = c; t.w = d;
@@ -147,7 +189,7 @@ __device__ __forceinline__ void sw_atomic_add(float* p, float v) {
 
 __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[SW_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3, li = lane & 31, lh = lane >> 5;
 
     // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id; the column tiles that share an
@@ -181,9 +223,14 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[x][y][r] = 0.f; cor[x][y][r] = 0.f; }
 
+    // LDS: [A stage 0 | A stage 1 | W stage 0 | W stage 1]; every address below is ONE lane-dependent register plus a
+    // compile-time constant (stage, plane and row-block offsets sit in the instructions' offset fields: the loop keeps
+    // 128 accumulator and 72 fragment registers live, there is no room for a register per address)
+    constexpr int A_ST = SW_A_BYTES, W_0 = 2 * SW_A_BYTES, W_ST = SW_W_BYTES;
+
     // ---- activation tile: thread -> rows ar, ar + 64, four consecutive k at 4 * akq
     const int ar = tid >> 3, akq = tid & 7;
-    size_t abase[2];
+    const float* pa[2];
     bool aok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -192,27 +239,20 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         // (the list is read unconditionally -- a dummy word of A itself without one -- and selected afterwards)
         const gbl_i32_ptr q = aidx ? (gbl_i32_ptr)aidx : (gbl_i32_ptr)g.A;
         const int t = q[(aidx && aok[i]) ? r : 0];
-        abase[i] = (size_t)(aok[i] ? (aidx ? t : r) : 0) * p.lda;
+        pa[i] = g.A + (size_t)(aok[i] ? (aidx ? t : r) : 0) * p.lda + 4 * akq;
     }
     auto loadA = [&](int kt, f32x4 (&v)[2]) {
-        const int k = kt * 32 + 4 * akq;
-        const bool kok = k < p.K;  // K % 4 == 0: a float4 is all-valid or all-invalid
+        const bool kok = kt * 32 + 4 * akq < p.K;  // K % 4 == 0: a float4 is all-valid or all-invalid
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bool ok = aok[i] && kok;
             // (always issued -- the K loop's waits count on exactly two loads per call -- and kept RAW: storeA zeroes
             // what is not live)
-            v[i] = sw_load16_untracked(g.A + (ok ? abase[i] + k : 0));
+            v[i] = sw_load16_untracked((aok[i] && kok) ? pa[i] + kt * 32 : g.A);
         }
     };
-    // byte offset of this thread's 8-B piece inside one plane of the A image
-    int aoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = ar + 64 * i;
-        aoff[i] = r * 64 + (((akq >> 1) ^ ((r >> 2) & 3)) << 4) + (akq & 1) * 8;
-    }
-    auto storeA = [&](unsigned char* ast, const f32x4 (&vr)[2], int kt) {
+    // byte offset of this thread's 8-B piece inside one plane of the A image ((r >> 2) & 3 is the same for r, r + 64)
+    const int aoff = ar * 64 + (((akq >> 1) ^ ((ar >> 2) & 3)) << 4) + (akq & 1) * 8;
+    auto storeA = [&](int stage, const f32x4 (&vr)[2], int kt) {
         const bool kok = kt * 32 + 4 * akq < p.K;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -224,99 +264,169 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
             const f32x4 r = v1 - __builtin_convertvector(h, f32x4);
             const bf16x4 m = __builtin_convertvector(r, bf16x4);
             const bf16x4 l = __builtin_convertvector(r - __builtin_convertvector(m, f32x4), bf16x4);
-            *reinterpret_cast<bf16x4*>(ast + aoff[i]) = h;
-            *reinterpret_cast<bf16x4*>(ast + SW_BM * 64 + aoff[i]) = m;
-            *reinterpret_cast<bf16x4*>(ast + 2 * SW_BM * 64 + aoff[i]) = l;
+            unsigned char* q = lds + aoff;
+            *reinterpret_cast<bf16x4*>(q + (stage * A_ST + i * 4096)) = h;
+            *reinterpret_cast<bf16x4*>(q + (stage * A_ST + i * 4096 + SW_BM * 64)) = m;
+            *reinterpret_cast<bf16x4*>(q + (stage * A_ST + i * 4096 + 2 * SW_BM * 64)) = l;
         }
     };
 
-    // ---- weight tile by LDS-DMA: 48 pieces of 1 KiB (3 planes x 16 blocks of 16 rows), 6 per wave
-    const unsigned char* Wimg = reinterpret_cast<const unsigned char*>(g.B);
-    const int wrow = lane >> 2, wc4 = lane & 3;
-    auto dmaW = [&](int kt, unsigned char* wst) {
+    // ---- weight tile by LDS-DMA: 48 pieces of 1 KiB (3 planes x 16 blocks of 16 rows), 6 per wave.  Source address =
+    //      wave-uniform piece base + one lane offset (row of the piece, swizzled chunk)
+    const unsigned char* Wimg = reinterpret_cast<const unsigned char*>(g.B) + (size_t)n0 * 64;
+    const unsigned wlane = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    auto dmaW = [&](int kt, int stage) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int pc = wid + 8 * j, pl = pc >> 4, row = (pc & 15) * 16 + wrow;
-            const unsigned char* src =
-                Wimg + ((size_t)(kt * 3 + pl) * p.Nimg + n0 + row) * 64 + ((wc4 ^ ((row >> 2) & 3)) << 4);
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(wst + pc * 1024), 16, 0, 0);
+            const int pc = wid + 8 * j, pl = pc >> 4, blk = pc & 15;
+            const unsigned char* src = Wimg + ((size_t)(kt * 3 + pl) * p.Nimg + blk * 16) * 64;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + wlane), (lds_void_ptr)(lds + W_0 + stage * W_ST + pc * 1024),
+                                             16, 0, 0);
         }
     };
 
-    // ---- fragments: 8 consecutive k (16 B) of one row and plane; row-dependent parts hoisted
-    int fa[2], fb[2], sa[2], sb[2];
+    // ---- fragments: 8 consecutive k (16 B) of one row and plane.  Chunk c = 2 h + lh of row r sits at
+    //      ((c ^ ((r >> 2) & 3)) << 4); (r >> 2) & 3 = (li >> 2) & 3 for every row block, and the second half of a
+    //      K-tile (h = 1) is the first half's address with bit 5 flipped
+    const int sw = (li >> 2) & 3;
+    const int lds0 = (int)(uintptr_t)(lds_void_ptr)lds;
+    int fra_at[2], frb_at[2][2];  // [h], [h][stage] (the weight stages are more than one offset field apart)
+    fra_at[0] = lds0 + (wm * 64 + li) * 64 + ((lh ^ sw) << 4);
+    fra_at[1] = fra_at[0] ^ 32;
+    frb_at[0][0] = lds0 + W_0 + (wn * 64 + li) * 64 + ((lh ^ sw) << 4);
+    frb_at[1][0] = frb_at[0][0] ^ 32;
+    frb_at[0][1] = frb_at[0][0] + W_ST;
+    frb_at[1][1] = frb_at[1][0] + W_ST;
+    // Fragment registers: ONE set for the activations (24 registers), TWO for the weights (48).  A K-tile is multiplied
+    // in two halves of 16 k; the fragments of the next half are requested behind the current half's MFMAs -- the
+    // weights into the other set, the activations of row block x once the MFMAs that read block x have been issued.
+    // The fragment reads are issued and awaited BY HAND (sw_ds_read16 / sw_wait_lds): while an LDS-DMA is in flight
+    // hipcc turns every wait for an LDS read into lgkmcnt(0) -- all reads, the ones just issued for the next half
+    // included.  LDS operations complete in issue order, so `lgkmcnt(N)` = "all but my N youngest are done".
+    // Measured (B=256, T=100 step, same box): first form (12 reads, lgkmcnt(0), 24 MFMAs, twice per K-tile, barrier at
+    // the end of the K-tile) 137 / 162 / 157 / 205 TFLOP/s at K = 256 / 512 / 528 / 131072; this form 143 / 168 /
+    // 163 / 219.  Pinning the order written here with sched_barrier (reads strictly ahead of each MFMA block) measured
+    // SLOWER than letting the scheduler place the MFMAs around the hand-issued reads (207 at long K): what is left is
+    // not LDS latency -- a diagnostic build without any fragment read runs at the same speed -- but the weight DMA's
+    // latency (one K-tile in flight is all 2 x 72 KiB allow) beside the per-K-tile barrier.
+    bf16x8 fra[2][3], frb[2][2][3];
+    auto readA = [&](auto xc, auto stc, auto hc) {
+        constexpr int x = decltype(xc)::value, st = decltype(stc)::value, h = decltype(hc)::value;
+        fra[x][0] = sw_ds_read16<st * A_ST + x * 2048>(fra_at[h]);
+        fra[x][1] = sw_ds_read16<st * A_ST + x * 2048 + SW_BM * 64>(fra_at[h]);
+        fra[x][2] = sw_ds_read16<st * A_ST + x * 2048 + 2 * SW_BM * 64>(fra_at[h]);
+    };
+    auto readB = [&](auto bufc, auto stc, auto hc) {
+        constexpr int buf = decltype(bufc)::value, st = decltype(stc)::value, h = decltype(hc)::value;
+        frb[buf][0][0] = sw_ds_read16<0>(frb_at[h][st]);
+        frb[buf][0][1] = sw_ds_read16<SW_BN * 64>(frb_at[h][st]);
+        frb[buf][0][2] = sw_ds_read16<2 * SW_BN * 64>(frb_at[h][st]);
+        frb[buf][1][0] = sw_ds_read16<2048>(frb_at[h][st]);
+        frb[buf][1][1] = sw_ds_read16<2048 + SW_BN * 64>(frb_at[h][st]);
+        frb[buf][1][2] = sw_ds_read16<2048 + 2 * SW_BN * 64>(frb_at[h][st]);
+    };
+    auto block = [&](int x, int buf) {
+#if SW_DBG & 4
+        return;
+#endif
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int ra = wm * 64 + x * 32 + li, rb = wn * 64 + x * 32 + li;
-        fa[x] = ra * 64; sa[x] = (ra >> 2) & 3;
-        fb[x] = rb * 64; sb[x] = (rb >> 2) & 3;
-    }
-    auto compute = [&](const unsigned char* ast, const unsigned char* wst) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2][3], b[2][3];
-            const int c = 2 * s + lh;
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[x][pl] = *reinterpret_cast<const bf16x8*>(ast + pl * SW_BM * 64 + fa[x] + ((c ^ sa[x]) << 4));
-                    b[x][pl] = *reinterpret_cast<const bf16x8*>(wst + pl * SW_BN * 64 + fb[x] + ((c ^ sb[x]) << 4));
-                }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {  // corrections smallest first; the leading product on its own
-                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], cor[x][y], 0, 0, 0);
-                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], cor[x][y], 0, 0, 0);
-                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], cor[x][y], 0, 0, 0);
-                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], cor[x][y], 0, 0, 0);
-                    cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], cor[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
-                }
+        for (int y = 0; y < 2; ++y) {  // corrections smallest first; the leading product on its own
+            cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][2], frb[buf][y][0], cor[x][y], 0, 0, 0);
+            cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][0], frb[buf][y][2], cor[x][y], 0, 0, 0);
+            cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][1], frb[buf][y][1], cor[x][y], 0, 0, 0);
+            cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][1], frb[buf][y][0], cor[x][y], 0, 0, 0);
+            cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][0], frb[buf][y][1], cor[x][y], 0, 0, 0);
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[x][0], frb[buf][y][0], acc[x][y], 0, 0, 0);
         }
     };
+    typedef std::integral_constant<int, 0> c0;
+    typedef std::integral_constant<int, 1> c1;
 
-    // ---- K loop: two stages, one barrier per K-tile; the next tile's activations travel through registers and are
-    //      split behind this tile's MFMAs, its weights stream in by DMA meanwhile
-    // Activations are requested TWO K-tiles ahead (two register sets that swap roles -- a copy would have to wait for
-    // the loads just requested); the weights' DMAs one K-tile ahead.  In every iteration the DMAs are issued first
-    // and the two activation loads last, so `s_waitcnt vmcnt(2)` means "my DMAs have landed" and lets the loads fly on.
-    // All waits on vector memory inside the loop are written by hand (see sw_load16_untracked).
+    // ---- K loop: two LDS stages, ONE barrier per K-tile, placed BETWEEN the two halves of the tile's MFMA work:
+    //   first half of K-tile k  : MFMAs on (k, first 16) | reads fragments (k, second 16) | splits and stores the
+    //                             activations of K-tile k+1 into the other stage
+    //   wait (my DMAs of k+1 landed, my LDS traffic done), barrier: stage k+1 is complete, stage k is dead
+    //   second half             : requests K-tile k+2's weights (DMA into the dead stage) and K-tile k+3's activations,
+    //                             MFMAs on (k, second 16) | reads fragments (k+1, first 16) from the other stage
+    // Activations travel through registers, requested two K-tiles before they are split (two register sets that swap
+    // roles); in every request group the 6 DMAs are issued before the 2 loads, so `vmcnt(8)` means "the loads of the
+    // group before the last have landed" and `vmcnt(2)` "the DMAs of the last group have landed".  All waits on
+    // vector memory inside the loop are written by hand (see sw_load16_untracked).  The stage is a compile-time
+    // constant of each copy of the body (K-tiles alternate between the two copies).
+    // Fragment reads in issue order per K-tile: [B h1: 6][A0 h1: 3][A1 h1: 3] barrier [B' h0: 6][A0' h0: 3][A1' h0: 3]
     f32x4 va[2], vb[2];
-    dmaW(kt0, lds + SW_A_BYTES);
+    dmaW(kt0, 0);
     loadA(kt0, vb);
     loadA(kt0 + 1, va);
     sw_wait_loads<2>(vb);  // (vb is younger than the DMAs: they have landed too; va's two loads fly on)
-    storeA(lds, vb, kt0);
+    storeA(0, vb, kt0);
+    if (kt0 + 1 < kt1) dmaW(kt0 + 1, 1);
+    loadA(kt0 + 2, vb);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // (bare: __syncthreads() carries a fence that waits for ALL vector-memory operations)
     asm volatile("" ::: "memory");
-    int cur = 0, kt = kt0;
-    // One iteration = 6 DMAs, then 2 loads, in that order.  `vs` was requested one iteration ago, so 8 younger
-    // operations may still be outstanding when it is split; at the barrier the 2 loads of this iteration may.
-    auto iter = [&](int k, f32x4 (&vs)[2], f32x4 (&vl)[2]) {
-        unsigned char* nxt = lds + (cur ^ 1) * SW_STAGE;
-        dmaW(k + 1, nxt + SW_A_BYTES);
-        loadA(k + 2, vl);
-        __builtin_amdgcn_sched_barrier(0);  // (the requests go out before the MFMAs, not behind them)
-        compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
+    readB(c0(), c0(), c0());
+    readA(c0(), c0(), c0());
+    readA(c1(), c0(), c0());
+    // vs: the activations of K-tile k+1; leaves with those of k+3 requested.  ST: the stage K-tile k lives in
+    auto body = [&](int k, f32x4 (&vs)[2], auto stc) {
+        constexpr int ST = decltype(stc)::value;
+        typedef std::integral_constant<int, ST ^ 1> nxc;
+        readB(c1(), stc, c1());
+        sw_wait_lds<9>(fra[0], frb[0]);  // (the 9 youngest: A1 of this half, B of the next)
+        block(0, 0);
+        readA(c0(), stc, c1());
+        sw_wait_lds<9>(fra[1]);          // (the 9 youngest: B and A0 of the next half)
         sw_wait_loads<8>(vs);
-        storeA(nxt, vs, k + 1);
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        storeA(ST ^ 1, vs, k + 1);       // (VALU work the scheduler may spread between these MFMAs)
+        block(1, 0);
+        readA(c1(), stc, c1());
+        // my DMAs of K-tile k+1 have landed; all my LDS reads and writes are done: fragments of the second half in
+        // registers (no further wait before its MFMAs), nobody still reads the stage that is overwritten next
+        sw_wait_all_lds(fra, frb[1]);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        cur ^= 1;
+        if (k + 2 < kt1) dmaW(k + 2, ST);  // (skipped only in the last body: no counted wait follows it)
+        loadA(k + 3, vs);
+        readB(c0(), nxc(), c0());
+        block(0, 1);
+        readA(c0(), nxc(), c0());
+        block(1, 1);
+        readA(c1(), nxc(), c0());
     };
+    int kt = kt0, cur = 0;
     for (; kt + 2 < kt1; kt += 2) {
-        iter(kt, va, vb);
-        iter(kt + 1, vb, va);
+        body(kt, va, c0());
+        body(kt + 1, vb, c1());
     }
     if (kt + 1 < kt1) {
-        iter(kt, va, vb);  // (vb receives K-tile kt+2 = past the range: never used)
-        ++kt;
+        body(kt, va, c0());
+        cur = 1;
     }
-    compute(lds + cur * SW_STAGE, lds + cur * SW_STAGE + SW_A_BYTES);
+    {   // last K-tile of the range: nothing left to stage (ONE copy for both stages, so that the accumulators of the
+        // two ways into it meet in the same registers; its addresses take the stage at run time)
+        const int la = fra_at[1] + cur * A_ST, lw = frb_at[1][0] + cur * W_ST;
+        frb[1][0][0] = sw_ds_read16<0>(lw);
+        frb[1][0][1] = sw_ds_read16<SW_BN * 64>(lw);
+        frb[1][0][2] = sw_ds_read16<2 * SW_BN * 64>(lw);
+        frb[1][1][0] = sw_ds_read16<2048>(lw);
+        frb[1][1][1] = sw_ds_read16<2048 + SW_BN * 64>(lw);
+        frb[1][1][2] = sw_ds_read16<2048 + 2 * SW_BN * 64>(lw);
+        sw_wait_lds<9>(fra[0], frb[0]);
+        block(0, 0);
+        fra[0][0] = sw_ds_read16<0>(la);
+        fra[0][1] = sw_ds_read16<SW_BM * 64>(la);
+        fra[0][2] = sw_ds_read16<2 * SW_BM * 64>(la);
+        sw_wait_lds<9>(fra[1]);
+        block(1, 0);
+        fra[1][0] = sw_ds_read16<2048>(la);
+        fra[1][1] = sw_ds_read16<2048 + SW_BM * 64>(la);
+        fra[1][2] = sw_ds_read16<2048 + 2 * SW_BM * 64>(la);
+        sw_wait_lds<3>(fra[0], frb[1]);
+        block(0, 1);
+        sw_wait_lds<0>(fra[1]);
+        block(1, 1);
+    }
     // Untracked loads whose data is never used (K-tiles past the range) still write their registers when they land:
     // the registers must stay reserved until then, or the allocator hands them to a ds_read / MFMA operand that the
     // late write then clobbers.  Hence: wait for everything, then a (void) use of both sets.
