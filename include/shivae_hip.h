@@ -153,7 +153,10 @@ int shivae_plan_bind(shivae_plan* plan, void* workspace_dev, size_t workspace_by
 /* ---- the step ------------------------------------------------------------------------------ */
 /* replaces model(x, mask, beta, temp) + n_elbo.backward() (trainers.py:212-215,
  * base_missvae.py:144-231, shivae.py:72-154) for one contiguous batch of exactly cfg.B sequences.
- *   u, eps    : explicit noise (what samplers.py:25 torch.rand and :60 normal_() would draw)
+ *   u, eps    : explicit noise (what samplers.py:25 torch.rand and :60 normal_() would draw), [T][B][K] and
+ *               [T][B][Z]; or BOTH NULL: the scans draw it themselves (north_star kernel 2: "on-device Philox"),
+ *               see shivae_plan_set_noise_seed -- nothing is materialised, forward and reverse scan regenerate the
+ *               same numbers
  *   inv_batch : 1/B_total -- the batch mean of base_missvae.py:212; with micro-batches or data
  *               parallelism pass the GLOBAL batch so that gradients add up across calls/ranks
  *   losses_dev: 9 floats, ACCUMULATED (+=): n_elbo, nll_loss, kld, kld_q_z, kld_q_s, nll_real,
@@ -201,10 +204,23 @@ int shivae_scan_bwd(shivae_plan* plan, const float* x_dev, const float* u_dev, c
 int shivae_loss_reduce(shivae_plan* plan, float beta, float inv_batch, float* losses_dev, shivae_stream stream);
 
 /* ShiVAE.sample_from_prior (src/models/shivae.py:156-214): generation from the prior over plan.T steps for
- * plan.B sequences with explicit noise u[T][B][K] (Gumbel uniforms) and eps[T][B][Z].  Afterwards
+ * plan.B sequences with explicit noise u[T][B][K] (Gumbel uniforms) and eps[T][B][Z] (or both NULL: in-kernel
+ * noise, below).  Afterwards
  * shivae_get_output gives Z (the prior sample), Z_MEAN / Z_STD (prior mean / std), S, S_PROBS (the uniform
  * 1/K) and DEC_PARAMS. */
 int shivae_sample_prior(shivae_plan* plan, const float* u_dev, const float* eps_dev, float temp, shivae_stream stream);
+
+/* ---- in-kernel noise (samplers.py:23-30 torch.rand, samplers.py:57-62 normal_()) ---------------------------------
+ * Every entry point above that takes (u_dev, eps_dev) accepts NULL for both; the scans then compute
+ *   u[t][b][k], eps[t][b][n] = f(seed, row = t*B + b, index)
+ * with Philox4x32-10 (key = seed; counter = (row, index / 4, stream); uniforms ((x >> 9) + 0.5) 2^-23 in (0,1), normals
+ * by Box-Muller) where they need them: no noise tensor exists.  The seed is the plan's; set a NEW one before every
+ * step (same seed = same noise), and leave it alone between shivae_scan_fwd and shivae_scan_bwd of one step.  Rows
+ * are the plan's rows: two micro-batches or two ranks that must not share noise take different seeds. */
+int shivae_plan_set_noise_seed(shivae_plan* plan, uint64_t seed);
+/* the same streams written out: u_dev[rows][K], eps_dev[rows][Z] (either may be NULL).  A step with these tensors
+ * equals the step with (NULL, NULL) under the same seed bit for bit. */
+int shivae_noise_fill(uint64_t seed, int64_t rows, int K, int Z, float* u_dev, float* eps_dev, shivae_stream stream);
 
 /* copy one named output of the last step into dst_dev as [T][B][width] (unpadded) */
 int shivae_get_output(shivae_plan* plan, int which, float* dst_dev, shivae_stream stream);

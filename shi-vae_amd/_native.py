@@ -33,7 +33,7 @@ SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_init", "shivae_plan_se
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
            "shivae_set_gemm_split", "shivae_presplit_bytes", "shivae_presplit_weights", "shivae_gemm_nt_presplit", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
            "shivae_allreduce_grads",
-           "shivae_sample_prior", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
+           "shivae_sample_prior", "shivae_plan_set_noise_seed", "shivae_noise_fill", "shivae_get_output", "shivae_output_width", "shivae_get_persum", "shivae_heter_nll", "shivae_mc_impute", "shivae_kl_terms",
            "shivae_reparam_fwd", "shivae_reparam_bwd", "shivae_gemm", "shivae_zero", "shivae_sqnorm",
            "shivae_clip_adam", "shivae_scale_transform", "shivae_scale_inverse", "shivae_profile_start", "shivae_profile_active",
            "shivae_profile_stop", "shivae_debug_gemm_stamps"]
@@ -97,6 +97,8 @@ def lib():
     L.shivae_comm_destroy.argtypes = [vp]
     L.shivae_allreduce_grads.argtypes = [vp, i64, vp, i64, vp]
     L.shivae_sample_prior.argtypes = [vp, vp, vp, cf, vp]
+    L.shivae_plan_set_noise_seed.argtypes = [vp, C.c_uint64]
+    L.shivae_noise_fill.argtypes = [C.c_uint64, i64, ci, ci, vp, vp, vp]
     L.shivae_get_output.argtypes = [vp, ci, vp, vp]
     L.shivae_output_width.argtypes = [vp, ci]
     L.shivae_get_persum.argtypes = [vp, vp, vp]

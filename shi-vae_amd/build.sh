@@ -10,7 +10,7 @@ mkdir -p "$OBJ"
 pids=()
 for f in $SRC; do
   o="$OBJ/$(basename "$f" .hip).o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/csrc/common.h" -nt "$o" ] || [ "$HERE/csrc/cell_math.h" -nt "$o" ] \
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/csrc/common.h" -nt "$o" ] || [ "$HERE/csrc/cell_math.h" -nt "$o" ] || [ "$HERE/csrc/noise.h" -nt "$o" ] \
      || [ "$HERE/../include/shivae_hip.h" -nt "$o" ]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed \
         -c "$f" -o "$o" &

@@ -184,14 +184,15 @@ struct ScanWOff {
 
 // Row-major record buffers, row = t*B + b, leading dims padded: Hp/Zp/Kp (multiples of 16),
 // emb = [phi_z (Hp) | s (Kp) | h_prev (Hp)] with Ep = 2*Hp + Kp.  u/eps are the caller's unpadded
-// [T][B][K] / [T][B][Z].
+// [T][B][K] / [T][B][Z], or both null.
 struct ScanArgs {
     int T, B, H, Z, K, Hp, Zp, Kp, Ep;
     float temp;
     const float* wpack;
     int wlds_floats;  // size of wpack if the kernel may keep all of it in LDS (small models), else 0
     ScanWOff w;
-    const float *xs_pre, *ex_pre, *u, *eps;
+    const float *xs_pre, *ex_pre, *u, *eps;  // u == eps == nullptr: the scans draw the noise themselves (noise.h) under
+    unsigned long long seed;                 // this seed -- the SAME numbers in the forward and the reverse scan
     float *emb, *as_, *e1, *e2, *logits, *probs, *mu, *sd, *z, *gates, *cnew, *h_last;
     const float *d_emb, *dmu_ext, *dsd_ext, *dlg_kl;
     float *d_gates, *d_phiz_pre, *d_mu, *d_sd_pre, *d_e2_pre, *d_e1_pre, *d_lg_pre, *d_as_pre;
@@ -212,6 +213,8 @@ int launch_pack(const PackJob* wjobs_dev, int nw, const PackJob* bjobs_dev, int 
 int launch_scan(const ScanArgs& a, bool bwd, hipStream_t stream);
 // generation from the prior (shivae.py:156-214): writes emb, z, mu(=prior mean), sd(=prior std), probs(=1/K)
 int launch_scan_gen(const ScanArgs& a, hipStream_t stream);
+// u[rows][K] / eps[rows][Z] (either may be null) as the scans draw them under `seed`
+int launch_noise_fill(unsigned long long seed, long long rows, int K, int Z, float* u, float* eps, hipStream_t stream);
 
 // ---------------------------------------------------------------- misc (optim.hip)
 int launch_compact_emb(const float* emb, int Ep, int Hp, int Kp, int H, int K, float* embc, int ldc, int rows,

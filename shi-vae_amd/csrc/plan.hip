@@ -127,6 +127,7 @@ struct shivae_plan {
     GroupTable b_l0_d, b_l0_dr;  // layer-0 input gradient per attribute over its observed rows, added into the chunk's rows
     int demb_mode = 2;           // SHIVAE_DEMB: 0 "dense" (one GEMM over all attributes' column blocks), 1 "compact", 2 "auto"
     float obs_frac = -1.f;       // auto: observed fraction of the first row chunk this plan trained on (< 0: not seen yet)
+    unsigned long long noise_seed = 0;  // seed of the scans' in-kernel noise (calls with u == eps == nullptr)
     int l0_nmain = 0;
     GroupTable f_l0, f_l1, f_l2, f_h0, b_l1_w, b_l1_d, b_l2_w, b_l2_d, b_h0_w, b_h0_d;
     int compact = 1;  // mask-aware decoder in training steps (SHIVAE_COMPACT=0: dense)
@@ -626,7 +627,7 @@ static ScanArgs scan_args(shivae_plan* p, const float* u, const float* eps, floa
     a.Hp = p->Hp; a.Zp = p->Zp; a.Kp = p->Kp; a.Ep = p->Ep; a.temp = temp;
     a.wpack = p->wsf("wpack"); a.w = p->woff;
     a.wlds_floats = (int)p->wpack_floats;
-    a.xs_pre = p->wsf("xs_pre"); a.ex_pre = p->wsf("ex_pre"); a.u = u; a.eps = eps;
+    a.xs_pre = p->wsf("xs_pre"); a.ex_pre = p->wsf("ex_pre"); a.u = u; a.eps = eps; a.seed = p->noise_seed;
     a.emb = p->wsf("emb"); a.as_ = p->wsf("as"); a.e1 = p->wsf("e1"); a.e2 = p->wsf("e2");
     a.logits = p->wsf("logits"); a.probs = p->wsf("probs"); a.mu = p->wsf("mu"); a.sd = p->wsf("sd");
     a.z = p->wsf("z"); a.gates = p->wsf("gates"); a.cnew = p->wsf("cnew"); a.h_last = nullptr;
@@ -1199,7 +1200,8 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
 
 int shivae_elbo_step(shivae_plan* p, const float* x, const uint8_t* mask, const float* u, const float* eps, float beta,
                      float temp, float inv_batch, int flags, float* losses, shivae_stream stream) {
-    SV_REQUIRE(p && x && mask && u && eps && losses, "elbo_step: null argument");
+    SV_REQUIRE(p && x && mask && losses, "elbo_step: null argument");
+    SV_REQUIRE((u != nullptr) == (eps != nullptr), "elbo_step: u and eps are given together, or both null (in-kernel noise)");
     if (!p->bound) {
         set_error("elbo_step: plan has no workspace/parameters bound (call shivae_plan_bind)");
         return SHIVAE_ERR_UNBOUND;
@@ -1215,7 +1217,8 @@ int shivae_elbo_step(shivae_plan* p, const float* x, const uint8_t* mask, const 
     }
 
 int shivae_scan_fwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, shivae_stream stream) {
-    SV_REQUIRE(p && x && u && eps, "scan_fwd: null argument");
+    SV_REQUIRE(p && x, "scan_fwd: null argument");
+    SV_REQUIRE((u != nullptr) == (eps != nullptr), "scan_fwd: u and eps are given together, or both null (in-kernel noise)");
     SV_BOUND("scan_fwd");
     SV_REQUIRE(temp > 0.f, "scan_fwd: temperature must be > 0");
     p->last_flags = SHIVAE_STEP_FORWARD_ONLY;
@@ -1238,7 +1241,8 @@ int shivae_decoder_nll(shivae_plan* p, const float* x, const uint8_t* mask, floa
 
 int shivae_scan_bwd(shivae_plan* p, const float* x, const float* u, const float* eps, float temp, const float* d_emb,
                     const float* dmu, const float* dstd, const float* dlogits, shivae_stream stream) {
-    SV_REQUIRE(p && x && u && eps, "scan_bwd: null argument");
+    SV_REQUIRE(p && x, "scan_bwd: null argument");
+    SV_REQUIRE((u != nullptr) == (eps != nullptr), "scan_bwd: u and eps are given together, or both null (in-kernel noise)");
     SV_BOUND("scan_bwd");
     SV_REQUIRE(temp > 0.f, "scan_bwd: temperature must be > 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1266,13 +1270,25 @@ int shivae_loss_reduce(shivae_plan* p, float beta, float inv_batch, float* losse
 }
 
 int shivae_sample_prior(shivae_plan* p, const float* u, const float* eps, float temp, shivae_stream stream) {
-    SV_REQUIRE(p && u && eps, "sample_prior: null argument");
+    SV_REQUIRE(p, "sample_prior: null argument");
+    SV_REQUIRE((u != nullptr) == (eps != nullptr), "sample_prior: u and eps are given together, or both null (in-kernel noise)");
     if (!p->bound) {
         set_error("sample_prior: plan has no workspace/parameters bound (call shivae_plan_bind)");
         return SHIVAE_ERR_UNBOUND;
     }
     SV_REQUIRE(temp > 0.f, "sample_prior: temperature must be > 0");
     return generate(p, u, eps, temp, static_cast<hipStream_t>(stream));
+}
+
+int shivae_plan_set_noise_seed(shivae_plan* p, uint64_t seed) {
+    SV_REQUIRE(p, "plan_set_noise_seed: null plan");
+    p->noise_seed = seed;
+    return SHIVAE_OK;
+}
+
+int shivae_noise_fill(uint64_t seed, int64_t rows, int K, int Z, float* u, float* eps, shivae_stream stream) {
+    SV_REQUIRE(rows >= 0 && K >= 0 && Z >= 0, "noise_fill: negative extent");
+    return launch_noise_fill(seed, rows, K, Z, u, eps, static_cast<hipStream_t>(stream));
 }
 
 int shivae_output_width(const shivae_plan* p, int which) {

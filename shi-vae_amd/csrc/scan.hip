@@ -27,6 +27,7 @@
 
 #include "cell_math.h"
 #include "common.h"
+#include "noise.h"
 
 namespace shivae {
 
@@ -118,6 +119,30 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 __device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0.f ? v[0] : 0.f, a[1] > 0.f ? v[1] : 0.f, a[2] > 0.f ? v[2] : 0.f, a[3] > 0.f ? v[3] : 0.f}; }
 
+// ---- noise: the caller's tensors u[T][B][K] / eps[T][B][Z], or -- u == eps == nullptr -- the counter-based streams
+// of noise.h under ScanArgs::seed.  Same numbers in the forward scan, the reverse scan and noise_fill_kernel.
+__device__ __forceinline__ f32x4 sv_eps4(const ScanArgs& a, size_t row, int g, bool live) {  // eps[row][4g .. 4g+3]
+    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+    if (!live) return e;
+    if (a.eps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.Z) e[r] = a.eps[row * a.Z + 4 * g + r];
+    } else {
+        const SvF4 t = sv_noise_eps4(a.seed, row, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.Z) e[r] = t.v[r];
+    }
+    return e;
+}
+__device__ __forceinline__ float sv_u1(const ScanArgs& a, size_t row, int k) {  // u[row][k]
+    if (a.u) return a.u[row * a.K + k];
+    const SvF4 t = sv_noise_u4(a.seed, row, k >> 2);
+    const int e = k & 3;
+    return e == 0 ? t.v[0] : e == 1 ? t.v[1] : e == 2 ? t.v[2] : t.v[3];
+}
+
 // ---------------------------------------------------------------------------------- forward
 // Per timestep the serial chain is  a_s -> logits -> s -> e1 -> e2 -> (mu,std,z) -> phi_z -> gates.
 // Everything that needs only h_{t-1} (the h halves of a_s and e1, Whh h_{t-1}: half of the MFMA work)
@@ -180,18 +205,19 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             xs_pf[s] = ld ? ldg4(a.xs_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
             ex_pf[s] = ld ? ldg4(a.ex_pre + row * Hp + own[s] * 16 + 4 * q) : zero4;
         }
-        float eps_pf[4] = {0.f, 0.f, 0.f, 0.f}, u_pf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-        if (wid < ZT && live) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = wid * 16 + 4 * q + r;
-                if (n < a.Z) eps_pf[r] = a.eps[row * a.Z + n];
-            }
-        }
+        float u_pf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+        const f32x4 eps_pf = sv_eps4(a, row, wid * 4 + q, wid < ZT && live);
         if (wid == 0 && KT == 1 && live) {
+            if (a.u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * q + r < a.K) u_pf[r] = a.u[row * a.K + 4 * q + r];
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < a.K) u_pf[r] = a.u[row * a.K + 4 * q + r];
+            } else {
+                const SvF4 t = sv_noise_u4(a.seed, row, q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < a.K) u_pf[r] = t.v[r];
+            }
         }
 
         // P0: a_s = relu(xs_pre + Wxs0[:, X:] h)   encoders.py:83 (x half hoisted);  e1 partial = We0[:, H+K:] h
@@ -270,14 +296,14 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 float m1 = -INFINITY, m2 = -INFINITY;
                 for (int k = 0; k < a.K; ++k) {
                     const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                    const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                    const float u = lv ? sv_u1(a, r, k) : 0.5f;
                     m1 = fmaxf(m1, l);
                     m2 = fmaxf(m2, (l + sv_gumbel(u)) / a.temp);
                 }
                 float s1 = 0.f, s2 = 0.f;
                 for (int k = 0; k < a.K; ++k) {
                     const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                    const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                    const float u = lv ? sv_u1(a, r, k) : 0.5f;
                     s1 += expf(l - m1);
                     s2 += expf((l + sv_gumbel(u)) / a.temp - m2);
                 }
@@ -285,7 +311,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                     float sv = 0.f;
                     if (k < a.K) {
                         const float l = lgbuf[qidx(k >> 4, (k >> 2) & 3, jj) + (k & 3)];
-                        const float u = lv ? a.u[r * a.K + k] : 0.5f;
+                        const float u = lv ? sv_u1(a, r, k) : 0.5f;
                         sv = expf((l + sv_gumbel(u)) / a.temp - m2) / s2;
                         if (lv) {
                             a.logits[r * Kp + k] = l;
@@ -344,13 +370,12 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             const int n = zt * 16 + 4 * q;
             const f32x4 mu = am[0] + ld4(Wb + a.w.b_mu + n);
             const f32x4 sp = as[0] + ld4(Wb + a.w.b_sd + n);
-            f32x4 sd, z;
+            f32x4 sd, z, ev = eps_pf;
+            if (zt != wid) ev = sv_eps4(a, row, zt * 4 + q, live);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sd[r] = sv_softplus(sp[r]);
-                float e = eps_pf[r];
-                if (zt != wid) e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
-                z[r] = e * sd[r] + mu[r];
+                z[r] = ev[r] * sd[r] + mu[r];
             }
             st4(zbuf + qidx(zt, q, j), z);
             if (live) {
@@ -460,13 +485,13 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
             const bool lv = bb < B;
             const size_t r = (size_t)t * B + (lv ? bb : 0);
             float m2 = -INFINITY;
-            for (int k = 0; k < a.K; ++k) m2 = fmaxf(m2, (lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp);
+            for (int k = 0; k < a.K; ++k) m2 = fmaxf(m2, (lq + sv_gumbel(lv ? sv_u1(a, r, k) : 0.5f)) / a.temp);
             float s2 = 0.f;
-            for (int k = 0; k < a.K; ++k) s2 += expf((lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp - m2);
+            for (int k = 0; k < a.K; ++k) s2 += expf((lq + sv_gumbel(lv ? sv_u1(a, r, k) : 0.5f)) / a.temp - m2);
             for (int k = 0; k < Kp; ++k) {
                 float sv = 0.f;
                 if (k < a.K) {
-                    sv = expf((lq + sv_gumbel(lv ? a.u[r * a.K + k] : 0.5f)) / a.temp - m2) / s2;
+                    sv = expf((lq + sv_gumbel(lv ? sv_u1(a, r, k) : 0.5f)) / a.temp - m2) / s2;
                     if (lv) {
                         a.emb[r * Ep + Hp + k] = sv;
                         a.probs[r * Kp + k] = 1.f / (float)a.K;
@@ -507,11 +532,11 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
             const f32x4 mu = am[0] + ld4(Wb + a.w.b_pm + n);
             const f32x4 sp = as[0] + ld4(Wb + a.w.b_ps + n);
             f32x4 sd, z;
+            const f32x4 ev = sv_eps4(a, row, zt * 4 + q, live);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sd[r] = sv_softplus(sp[r]);
-                const float e = (live && n + r < a.Z) ? a.eps[row * a.Z + n + r] : 0.f;
-                z[r] = e * sd[r] + mu[r];
+                z[r] = ev[r] * sd[r] + mu[r];
             }
             st4(zbuf + qidx(zt, q, j), z);
             if (live) {
@@ -651,9 +676,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             z_dmu = ldg4(a.dmu_ext + row * Zp + n);
             z_dsd = ldg4(a.dsd_ext + row * Zp + n);
             z_sd = ldg4(a.sd + row * Zp + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < a.Z) z_eps[r] = a.eps[row * a.Z + n + r];
+            z_eps = sv_eps4(a, row, wid * 4 + q, true);
         }
 
         // B1: LSTM cell backward on the owned hidden units (elementwise, registers)
@@ -723,9 +746,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 xm = xs = sd = ep = zero4;
                 if (live) {
                     xm = ldg4(a.dmu_ext + row * Zp + n); xs = ldg4(a.dsd_ext + row * Zp + n); sd = ldg4(a.sd + row * Zp + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < a.Z) ep[r] = a.eps[row * a.Z + n + r];
+                    ep = sv_eps4(a, row, zt * 4 + q, true);
                 }
             }
             f32x4 dmu = acc[0] + xm, dsd = zero4;
@@ -1005,6 +1026,42 @@ int launch_scan_gen(const ScanArgs& a, hipStream_t stream) {
         case 4: return launch_gen_t<4, 256>(a, nw, stream);
         default: return launch_gen_t<8, 256>(a, nw, stream);
     }
+}
+
+// ---------------------------------------------------------------------------------- noise as tensors
+// The streams the scans draw in-kernel under `seed` (noise.h), written out: u[rows][K], eps[rows][Z].  For tests and
+// for callers that want to look at, or replay, the noise of a step.
+__global__ __launch_bounds__(256) void noise_fill_kernel(unsigned long long seed, long long rows, int K, int Z, float* __restrict__ u,
+                                                         float* __restrict__ eps) {
+    const int gk = (K + 3) >> 2, gz = (Z + 3) >> 2, per = gk + gz;
+    const long long total = rows * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / per;
+        const int g = (int)(i % per);
+        if (g < gk) {
+            if (!u) continue;
+            const SvF4 t = sv_noise_u4(seed, (unsigned long long)row, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < K) u[row * K + 4 * g + r] = t.v[r];
+        } else {
+            if (!eps) continue;
+            const int gg = g - gk;
+            const SvF4 t = sv_noise_eps4(seed, (unsigned long long)row, gg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * gg + r < Z) eps[row * Z + 4 * gg + r] = t.v[r];
+        }
+    }
+}
+
+int launch_noise_fill(unsigned long long seed, long long rows, int K, int Z, float* u, float* eps, hipStream_t stream) {
+    if (rows <= 0 || (K <= 0 && Z <= 0)) return SHIVAE_OK;
+    const long long total = rows * (((K + 3) >> 2) + ((Z + 3) >> 2));
+    const int grid = (int)std::min<long long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(noise_fill_kernel, dim3(grid), dim3(256), 0, stream, seed, rows, K, Z, u, eps);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
 }
 
 }  // namespace shivae

@@ -13,7 +13,9 @@ Differences that are deliberate (and documented in DESIGN.md):
     out by the native plan so that per-attribute decoder weights are stacked for grouped GEMMs;
   * forward+backward are fused: ``model(...)`` in training mode already computes the gradients,
     ``loss['n_elbo'].backward()`` publishes them to ``p.grad``;
-  * noise is explicit.  By default it is drawn on the device (``noise_mode='device'``);
+  * noise: by default the scans draw it in-kernel from a counter-based generator (``noise_mode='device'``:
+    csrc/noise.h, Philox4x32-10, seeded from torch's CPU generator; no noise tensor exists);
+    ``noise_mode='torch'`` draws tensors with torch.rand / torch.randn on the device;
     ``noise_mode='reference'`` replays the reference's CPU stream (torch.rand(B,K) then normal_(B,Z)
     per timestep, samplers.py:25,60) so that ``torch.manual_seed`` reproduces the reference exactly;
     ``set_noise(u, eps)`` injects tensors for the next call.
@@ -76,6 +78,7 @@ class ShiVAE(nn.Module):
         self.h_dim, self.z_dim, self.s_dim, self.n_layers = int(h_dim), int(z_dim), int(s_dim), 1
 
         self.noise_mode = 'device'
+        self.max_micro_batch = None  # cap on the per-call batch (default: whatever fits the memory budget)
         self.print_losses = False   # the reference prints one line per forward (base_missvae.py:163)
         self.check_nan = True       # base_missvae.py:223-228 (one host sync per forward)
         self.workspace_limit_bytes = int(float(os.environ.get("SHIVAE_WS_GB", "0")) * 1e9) or None
@@ -288,8 +291,9 @@ class ShiVAE(nn.Module):
         return int(total - max(0.15 * total, reserve + 4e9))
 
     def micro_batch(self, T, B):
-        """Largest per-call batch whose workspace fits the budget (callers' B is split into these)."""
-        bm = B
+        """Largest per-call batch whose workspace fits the budget (callers' B is split into these);
+        ``max_micro_batch`` caps it (a multiple of the 16-sequence scan tile)."""
+        bm = B if not self.max_micro_batch else min(B, max(16, int(self.max_micro_batch) // 16 * 16))
         # a split batch also needs contiguous copies of each micro-batch's x, mask, u, eps slices
         slices = lambda b: 0 if b >= B else T * b * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
         while True:
@@ -327,7 +331,11 @@ class ShiVAE(nn.Module):
         """Noise for the NEXT step: u[T,B,K] in [0,1) (Gumbel), eps[T,B,Z] ~ N(0,1)."""
         self._pending_noise = (u, eps)
 
-    def _draw_noise(self, T, B):
+    def _draw_noise(self, T, B, tensors=False):
+        """-> (u, eps, seed).  ``noise_mode='device'`` (default): (None, None, seed) -- the scans draw their noise
+        in-kernel from a counter-based generator under `seed` (csrc/noise.h), nothing is materialised; `seed` comes
+        from torch's CPU generator, so ``torch.manual_seed`` fixes the run.  ``tensors=True`` asks for the same
+        streams as tensors (captured steps replay fixed kernel arguments, so they take their noise from buffers)."""
         dev = self._flat.device
         if self._pending_noise is not None:
             u, eps = self._pending_noise
@@ -335,15 +343,39 @@ class ShiVAE(nn.Module):
             u = torch.as_tensor(u, dtype=torch.float32, device=dev).contiguous()
             eps = torch.as_tensor(eps, dtype=torch.float32, device=dev).contiguous()
             assert tuple(u.shape) == (T, B, self.s_dim) and tuple(eps.shape) == (T, B, self.z_dim)
-            return u, eps
+            return u, eps, 0
         if self.noise_mode == 'reference':
             u = torch.empty(T, B, self.s_dim)
             eps = torch.empty(T, B, self.z_dim)
             for t in range(T):  # samplers.py:25 then :60, per timestep, CPU generator
                 u[t] = torch.rand(B, self.s_dim)
                 eps[t] = torch.FloatTensor(B, self.z_dim).normal_()
-            return u.to(dev), eps.to(dev)
-        return (torch.rand(T, B, self.s_dim, device=dev), torch.randn(T, B, self.z_dim, device=dev))
+            return u.to(dev), eps.to(dev), 0
+        if self.noise_mode == 'torch':
+            return torch.rand(T, B, self.s_dim, device=dev), torch.randn(T, B, self.z_dim, device=dev), 0
+        assert self.noise_mode == 'device', "noise_mode is 'device', 'torch' or 'reference'"
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        seed = (seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 64 - 1)  # (ranks under one torch seed draw different noise)
+        if tensors:
+            u, eps = self.noise_tensors(seed, T, B)
+            return u, eps, seed
+        return None, None, seed
+
+    def noise_tensors(self, seed, T, B):
+        """u[T,B,K], eps[T,B,Z] exactly as the scans draw them in-kernel under `seed` for a (T, B) batch
+        (shivae_noise_fill): ``set_noise(*model.noise_tensors(seed, T, B))`` replays a ``noise_mode='device'`` step."""
+        dev = self._flat.device
+        u = torch.empty(T, B, self.s_dim, device=dev)
+        eps = torch.empty(T, B, self.z_dim, device=dev)
+        N.check(N.lib().shivae_noise_fill(int(seed), T * B, self.s_dim, self.z_dim, N.ptr(u), N.ptr(eps), N.stream()))
+        return u, eps
+
+    @staticmethod
+    def _mb_seed(seed, i):
+        """seed of micro-batch i of a step (rows are per micro-batch: each takes a stream of its own)"""
+        return (seed + 0xD1B54A32D192ED03 * i) & (2 ** 64 - 1)
 
     # ------------------------------------------------------------------ the step
     def _step(self, x, mask, beta, temp, grad, keep_params=False, inv_batch=None, collect=None):
@@ -356,7 +388,6 @@ class ShiVAE(nn.Module):
             mask = mask != 0
         T, B, X = x.shape
         assert X == self.x_dim, "x has %d columns, types_list implies %d" % (X, self.x_dim)
-        u, eps = self._draw_noise(T, B)
         inv_batch = 1.0 / B if inv_batch is None else float(inv_batch)
         if grad and self._pending_reduce:
             # A second training forward before allreduce_grads() (gradient accumulation): the decoder buckets of the
@@ -371,9 +402,12 @@ class ShiVAE(nn.Module):
         bm = self.micro_batches(T, B)[0]
         self._slice_reserve = 0 if bm >= B else T * bm * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
         self._grow_chunk(T, min(bm, B))
-        if self._graph_eligible(T, B, bm, collect):
+        graphed = self._graph_eligible(T, B, bm, collect)
+        u, eps, seed = self._draw_noise(T, B, tensors=graphed)
+        if graphed:
             done = self._step_graphed(x, mask, u, eps, float(beta), float(temp), inv_batch, flags)
             if done is not None:
+                self._last["seed"] = seed
                 return done, {}
         outs = {w: [] for w in (collect or [])}
         persum = []
@@ -387,7 +421,10 @@ class ShiVAE(nn.Module):
                 xs, ms, us, es = x.contiguous(), mask.contiguous(), u, eps
             else:
                 xs, ms = x[:, b0:b1].contiguous(), mask[:, b0:b1].contiguous()
-                us, es = u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous()
+                if u is not None:
+                    us, es = u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous()
+            if u is None:  # in-kernel noise: nothing to slice, one seed per micro-batch
+                N.check(L.shivae_plan_set_noise_seed(plan.h, self._mb_seed(seed, b0 // bm)))
             if grad and b1 == B and self.overlap_allreduce and self._dp_backend() == "nccl" and not self._pending_reduce:
                 # last micro-batch of a data-parallel step, phase by phase (== shivae_elbo_step): the decoder's
                 # gradients are final once its last row chunk is done
@@ -410,7 +447,7 @@ class ShiVAE(nn.Module):
             N.check(L.shivae_get_persum(plan.h, N.ptr(ps), N.stream()))
             persum.append(ps)
         outs = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
-        self._last = dict(u=u, eps=eps, persum=torch.cat(persum) if persum else None)
+        self._last = dict(u=u, eps=eps, seed=seed, persum=torch.cat(persum) if persum else None)
         return losses, outs
 
     # ------------------------------------------------------------------ captured steps (small, launch-bound models)
@@ -664,7 +701,7 @@ class ShiVAE(nn.Module):
         self._require_gpu()
         dev = self._flat.device
         T, B = int(ts), int(batch_size)
-        u, eps = self._draw_noise(T, B)
+        u, eps, seed = self._draw_noise(T, B)
         O, L = N.O, N.lib()
         bm = self.micro_batches(T, B)[0]
         want = [O["Z"], O["Z_MEAN"], O["Z_STD"], O["S"], O["S_PROBS"], O["DEC_PARAMS"]]
@@ -672,7 +709,11 @@ class ShiVAE(nn.Module):
         for b0 in range(0, B, bm):
             b1 = min(B, b0 + bm)
             plan = self._activate(T, b1 - b0)
-            us, es = (u, eps) if (b0 == 0 and b1 == B) else (u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous())
+            if u is None:  # in-kernel noise
+                us = es = None
+                N.check(L.shivae_plan_set_noise_seed(plan.h, self._mb_seed(seed, b0 // bm)))
+            else:
+                us, es = (u, eps) if (b0 == 0 and b1 == B) else (u[:, b0:b1].contiguous(), eps[:, b0:b1].contiguous())
             N.check(L.shivae_sample_prior(plan.h, N.ptr(us), N.ptr(es), float(temp), N.stream()))
             for w in want:
                 o = torch.empty(T, b1 - b0, plan.output_width(w), dtype=torch.float32, device=dev)
@@ -681,7 +722,7 @@ class ShiVAE(nn.Module):
         o = {w: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for w, v in outs.items()}
         z_prior_tup = [o[O["Z"]], o[O["Z_MEAN"]], o[O["Z_STD"]]]
         s_tup = [o[O["S"]], o[O["S_PROBS"]]]
-        self._last = dict(u=u, eps=eps, persum=None, dec_params=o[O["DEC_PARAMS"]])
+        self._last = dict(u=u, eps=eps, seed=seed, persum=None, dec_params=o[O["DEC_PARAMS"]])
         return z_prior_tup, s_tup, self._likes_from_params(o[O["DEC_PARAMS"]])
 
     @torch.no_grad()
