@@ -410,13 +410,13 @@ def main():
     value = B * T / med
 
     prof_ms = prof_dt * 1e3  # wall time of the profiled step
-    gemms = [p for p in prof if p["id"] < 18 or p["id"] == 24]
+    gemms = [p for p in prof if p["id"] < 18 or p["id"] in (24, 25)]
     dom = max(gemms, key=lambda p: p["ms"]) if gemms else None
     roof = None
     if dom:
         ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12
         traffic, tsrc = pmc_traffic(a.config, B, T, dom["name"])
-        split_kernel = dom["id"] == 24 or dom["id"] % 6 == 5
+        split_kernel = dom["id"] in (24, 25) or dom["id"] % 6 == 5
         peak = PEAK_SPLIT_TFLOPS if split_kernel else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
@@ -436,7 +436,7 @@ def main():
         if 20 <= p["id"] <= 23:
             e.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
         else:
-            pk = PEAK_SPLIT_TFLOPS if (p["id"] == 24 or (p["id"] < 18 and p["id"] % 6 == 5)) else PEAK_F32_MFMA_TFLOPS
+            pk = PEAK_SPLIT_TFLOPS if (p["id"] in (24, 25) or (p["id"] < 18 and p["id"] % 6 == 5)) else PEAK_F32_MFMA_TFLOPS
             e.update(bound="mfma", achieved=rate / 1e12, peak=pk, unit="TFLOP/s", frac=rate / 1e12 / pk)
         others.append(e)
     out = {"metric": "train sequence-timesteps/sec (ELBO fwd+bwd)", "value": value, "unit": "sequence-timesteps/s",

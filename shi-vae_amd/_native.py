@@ -205,7 +205,7 @@ def profile_name(i):
     if i < 18:
         return "gemm_kernel<%s,%s>" % (_LAYOUTS[i // 6], _TILES[i % 6])
     return {18: "scan_fwd_kernel", 19: "scan_bwd_kernel", 20: "heter_nll_kernel", 21: "kl_kernel", 22: "head_fwd_kernel",
-            23: "head_bwd_kernel", 24: "gemm_split_nt_kernel<128x256, pre-split W>"}[i]
+            23: "head_bwd_kernel", 24: "gemm_split_nt_kernel<128x256, pre-split W>", 25: "gemm_split_tn_kernel<128x256x16>"}[i]
 
 
 def profile_start():

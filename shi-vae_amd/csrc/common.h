@@ -35,7 +35,7 @@ void set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- per-kernel HIP-event profiler (plan.hip)
 // ids 0..17: gemm_kernel variants = layout*6 + tile (0: 256x32, 1: 32x256, 2: 256x64, 3: 64x256, 4: 128x128, 5: 128x128 split-bf16)
-enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_SPLITW_NT = 24, PROF_COUNT = 25 };
+enum ProfId { PROF_SCAN_FWD = 18, PROF_SCAN_BWD = 19, PROF_NLL = 20, PROF_KL = 21, PROF_HEADS_FWD = 22, PROF_HEADS_BWD = 23, PROF_SPLITW_NT = 24, PROF_SPLIT_TN = 25, PROF_COUNT = 26 };
 void prof_begin(int id, double work, hipStream_t s);  // work: flops (gemm, scan) or algorithmic bytes (nll, kl)
 void prof_end(hipStream_t s);
 void prof_shape(int M, int N, int K, int G);  // optional detail for the next prof_begin
@@ -106,6 +106,10 @@ size_t presplit_bytes(int N, int K);               // bytes of the image of one 
 int launch_presplit(const float* W, int N, int K, int ld, int batch, size_t in_stride, void* img, hipStream_t stream);
 bool split_nt_fits(const GemmDesc& d);
 int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                         hipStream_t stream);
+// ---- split-mode TN GEMM on 128 x 256 x 16 tiles (gemm_split.hip): the weight gradients
+bool split_tn_fits(const GemmDesc& d);
+int launch_gemm_split_tn(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
                          hipStream_t stream);
 
 // bias gradient: out[g][n] += sum_m Y_g[m*ld + n]

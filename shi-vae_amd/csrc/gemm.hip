@@ -60,12 +60,11 @@ __device__ __forceinline__ void gatomic_add(float* p, float v) {
 }
 
 // ---- fp32 products on the bf16 matrix cores ("split" mode, SHIVAE_GEMM_SPLIT / shivae_set_gemm_split) ----------
-// An fp32 value is the exact sum of three bf16 values when each is taken by TRUNCATION: hi = upper 16 bits of x,
-// mid = upper 16 bits of (x - hi), lo = upper 16 bits of (x - hi - mid) -- 3 x 8 significand bits = the 24 of fp32,
-// every subtraction exact.  a*b is then accumulated in fp32 as the six bf16 products whose magnitude is >= 2^-16 of
-// the leading one (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi); the dropped ones (mid*lo, lo*mid, lo*lo) are
-// <= 2^-23 |a b|, the size of ONE fp32 rounding of the product.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
-// the fp32-input MFMA, so six of them per product still give 2.67x its throughput.
+// An fp32 value is the exact sum of three bf16 values: hi = bf16_rn(x), mid = bf16_rn(x - hi), lo = x - hi - mid
+// (every subtraction exact, lo fits 8 bits).  a*b is then accumulated in fp32 as the six bf16 products whose magnitude
+// is >= 2^-16 of the leading one -- hi*hi into the main accumulator, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi into a second
+// one that is added at the end; the dropped ones (mid*lo, lo*mid, lo*lo) are <= 2^-26 |a b|.  v_mfma_f32_32x32x16_bf16
+// runs at 16x the rate of the fp32-input MFMA, so six of them per product still give 2.67x its throughput.
 // LDS images of a split tile (bf16, built when the fp32 registers are parked in LDS):
 //   K-contiguous operand  : [rows][104] halves = hi[32] | mid[32] | lo[32] | pad[8]; a lane's fragment of one plane
 //                           (8 consecutive k) is one ds_read_b128; 208-B rows are conflict-free for them
@@ -892,6 +891,12 @@ int launch_gemm(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, con
     // vector epilogue: whole float4 pieces of C (and aux) rows must be addressable and 16-B aligned
     p.vecC = (d.ldc % 4 == 0) && (d.N % 4 == 0) && (d.c_aligned || (!groups_dev && aligned16(g0.C))) &&
              (!(d.epi & EPI_MASK) || (d.ldaux % 4 == 0 && (d.c_aligned || (!groups_dev && aligned16(g0.aux)))));
+    if (d.layout == GEMM_TN && gemm_split_on() && split_tn_fits(d) &&
+        (groups_dev ? d.c_aligned != 0 : (aligned16(g0.A) && aligned16(g0.B) && aligned16(g0.C)))) {
+        // split mode, weight-gradient shapes: the 128 x 256 x 16 two-stage kernel of gemm_split.hip
+        static const bool on = [] { const char* f = getenv("SHIVAE_SPLIT_TN"); return !f || atoi(f) != 0; }();
+        if (on) return launch_gemm_split_tn(d, groups_dev, ngroups, g0, stream);
+    }
     switch (d.layout) {
         case GEMM_NT: return launch_layout<true, true>(p, ngroups, stream);
         case GEMM_NN: return launch_layout<true, false>(p, ngroups, stream);

@@ -108,10 +108,10 @@ struct SplitNtParams {
     GemmGroup g0;
 };
 
-__device__ __forceinline__ GemmGroup sw_load_group(const SplitNtParams& p, int gi) {
-    if (!p.groups) return p.g0;
+__device__ __forceinline__ GemmGroup sw_load_group(const GemmGroup* groups, const GemmGroup& g0, int gi) {
+    if (!groups) return g0;
     typedef const unsigned long long __attribute__((address_space(4))) * const_u64_ptr;
-    const_u64_ptr q = (const_u64_ptr)(uintptr_t)(p.groups + __builtin_amdgcn_readfirstlane(gi));
+    const_u64_ptr q = (const_u64_ptr)(uintptr_t)(groups + __builtin_amdgcn_readfirstlane(gi));
     GemmGroup g;
     g.A = reinterpret_cast<const float*>(q[0]);
     g.B = reinterpret_cast<const float*>(q[1]);
@@ -178,6 +178,14 @@ __device__ __forceinline__ void sw_wait_all_lds(bf16x8 (&a)[2][3], bf16x8 (&b)[2
                  : "memory");
 }
 
+// the four bf16 of a packed vector back as floats, by bit operations on the two packed dwords (left to itself hipcc
+// CONVERTS every element a second time, unpacked, to get these: 7.5 instead of 5.5 VALU instructions per split element)
+__device__ __forceinline__ f32x4 sw_unpack_bf16x4(bf16x4 h) {
+    const uint2 u = __builtin_bit_cast(uint2, h);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+}
+
 __device__ __forceinline__ void sw_gstore4(float* p, float a, float b, float c, float d) {
     f32x4 t;
     t.x = a; t.y = b; t.z = c; t.w = d;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
     if (u >= p.nty * p.nz) return;
     const int by = u % p.nty, bz = u / p.nty;
     const int gidx = bz / p.splitk, ks = bz % p.splitk;
-    const GemmGroup g = sw_load_group(p, gidx);
+    const GemmGroup g = sw_load_group(p.groups, p.g0, gidx);
     const int m0 = by * SW_BM, n0 = bx * SW_BN;
     int Mrows = p.M;
     const int *aidx = nullptr, *cidx = nullptr;
@@ -261,9 +269,9 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
             f32x4 v1;
             v1.x = ok ? t.x : 0.f; v1.y = ok ? t.y : 0.f; v1.z = ok ? t.z : 0.f; v1.w = ok ? t.w : 0.f;
             const bf16x4 h = __builtin_convertvector(v1, bf16x4);
-            const f32x4 r = v1 - __builtin_convertvector(h, f32x4);
+            const f32x4 r = v1 - sw_unpack_bf16x4(h);
             const bf16x4 m = __builtin_convertvector(r, bf16x4);
-            const bf16x4 l = __builtin_convertvector(r - __builtin_convertvector(m, f32x4), bf16x4);
+            const bf16x4 l = __builtin_convertvector(r - sw_unpack_bf16x4(m), bf16x4);
             unsigned char* q = lds + aoff;
             *reinterpret_cast<bf16x4*>(q + (stage * A_ST + i * 4096)) = h;
             *reinterpret_cast<bf16x4*>(q + (stage * A_ST + i * 4096 + SW_BM * 64)) = m;
@@ -546,6 +554,301 @@ int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngr
     prof_shape(d.M, d.N, d.K, ngroups);
     prof_begin(PROF_SPLITW_NT, 2.0 * d.M * d.N * (double)d.K * ngroups, stream);
     hipLaunchKernelGGL(gemm_split_nt_kernel, dim3((unsigned)nlin), dim3(SW_NT), 0, stream, p);
+    prof_end(stream);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// =====================================================================================================================
+// Split-mode TN GEMM: C[M,N] (+)= A[K,M]^T B[K,N], the decoder's weight gradients (dY^T x activations, K = the rows of
+// a chunk; decoders.py:60-66,127-171 under autograd).  Both operands are activations, so both are split in the
+// kernel -- but ONCE per 128 x 256 output tile and with the split of the next K-tile running behind the current
+// K-tile's MFMAs:
+//   tile 128 x 256 x 16 on 8 waves (2 x 4, 64 x 64 per wave, two accumulator sets), one workgroup per CU;
+//   two LDS stages of 42 KiB, ONE barrier per K-tile; a thread owns a 4(k) x 4(m) block of one operand: four 16-B
+//   global loads, requested two K-tiles ahead into one of two register sets, split in registers, stored as one 8-B
+//   piece per row and plane;
+//   LDS image (gemm.hip, row-contiguous operands): [plane][k-quad][row & 3][row >> 2 (+8)][4 bf16]: a fragment (8 k of
+//   one row) is two ds_read_b64, stores and reads are conflict-free.
+// The generic split kernel (gemm.hip: 128 x 128 x 32 on 4 waves, ONE LDS stage, two barriers per K-tile, two
+// workgroups per CU) splits every operand element once per 128 output columns and overlaps its split phase only with
+// the other workgroup of the CU: 143-156 TFLOP/s on the weight-gradient shapes of cfg3.
+// Takes: M % 128 == 0, N % 256 == 0, 16-B aligned rows; EPI_ATOMIC (split-K), EPI_ADDC or plain store; ragged K
+// (device-side count) and row lists for both operands (the mask-aware decoder).
+constexpr int ST_BM = 128, ST_BN = 256, ST_KT = 16, ST_NT = 512;
+constexpr int ST_QA = ST_BM / 4 + 8, ST_QB = ST_BN / 4 + 8;          // row-quad strides of the (row & 3) blocks
+constexpr int ST_PA = 4 * 4 * ST_QA * 8, ST_PB = 4 * 4 * ST_QB * 8;  // bytes per plane (4 k-quads x 4 x Q x 8 B)
+constexpr int ST_A_BYTES = 3 * ST_PA, ST_B_BYTES = 3 * ST_PB;
+constexpr int ST_STAGE = ST_A_BYTES + ST_B_BYTES;                    // 43 008 B
+constexpr int ST_LDE = ST_BN + 4;
+constexpr int ST_LDS = ST_BM * ST_LDE * 4 > 2 * ST_STAGE ? ST_BM * ST_LDE * 4 : 2 * ST_STAGE;  // 133 120 B (C staging)
+
+struct SplitTnParams {
+    int M, N, K, lda, ldb, ldc, epi, ragged, splitk, kchunk;
+    int ntx, nty, nz;
+    const GemmGroup* groups;
+    GemmGroup g0;
+};
+
+
+template <bool LIST>  // LIST: both operands' K rows come through row lists (the mask-aware decoder's layer 0)
+__global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3, li = lane & 31, lh = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = slot % p.ntx, u = (slot / p.ntx) * 8 + xcd;
+    if (u >= p.nty * p.nz) return;
+    const int by = u % p.nty, bz = u / p.nty;
+    const int gidx = bz / p.splitk, ks = bz % p.splitk;
+    const GemmGroup g = sw_load_group(p.groups, p.g0, gidx);
+    const int m0 = by * ST_BM, n0 = bx * ST_BN;
+    int Kext = p.K, kchunk = p.kchunk;
+    const int *aidx = nullptr, *bidx = nullptr;
+    if (p.ragged) {
+        if (p.ragged & RAG_CNT) {  // the LIVE K, split evenly over the K-splits (whole K-tiles)
+            typedef const int __attribute__((address_space(4))) * const_int_ptr;
+            Kext = min(Kext, *(const_int_ptr)(uintptr_t)g.cnt);
+            kchunk = ((Kext + p.splitk - 1) / p.splitk + ST_KT - 1) & ~(ST_KT - 1);
+        }
+        if (p.ragged & RAG_AIDX) aidx = g.aidx;
+        if (p.ragged & RAG_BIDX) bidx = g.bidx;
+    }
+    const int kbeg = ks * kchunk;
+    if (kbeg >= Kext) return;  // (such launches accumulate: nothing to add)
+    const int kend = min(Kext, kbeg + kchunk);
+    const int nkt = (kend - kbeg + ST_KT - 1) / ST_KT;
+
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[x][y][r] = 0.f; cor[x][y][r] = 0.f; }
+
+    // ---- loader role of this thread: waves 0-1 the A tile (32 row quads x 4 k-quads), waves 2-5 the B tile (64 x 4),
+    //      waves 6-7 none: they run the same code on zeros and park them in the spare LDS behind the two stages (no
+    //      branch in the loop: the split arithmetic of the loaders is scheduled between the MFMAs of the same block).
+    //      Block = k-quad kq (4 k-rows) x row quad rq (4 consecutive m / n)
+    const bool isA = wid < 2, loader = wid < 6;
+    const int lt = isA ? tid : tid - 128;
+    const int rq = isA ? (lt & 31) : (lt & 63), kq = isA ? (lt >> 5) : ((lt >> 6) & 3);
+    const float* X = isA ? g.A : g.B;
+    const int ldx = isA ? p.lda : p.ldb;
+    const int* xidx = isA ? aidx : bidx;
+    const int col = (isA ? m0 : n0) + 4 * rq;
+    // LDS byte offset of this block's piece for row c = 0: ((kq * 4 + c) * Q + rq) * 8; planes ST_PA / ST_PB apart
+    const int Q = isA ? ST_QA : ST_QB;
+    const int soff = loader ? (isA ? 0 : ST_A_BYTES) + (kq * 4 * Q + rq) * 8 : 2 * ST_STAGE + (tid - 384) * 8;
+    const int sstage = loader ? ST_STAGE : 0;                      // (the spare area is not staged)
+    const int cstep = loader ? Q * 8 : 1024, pstep = loader ? (isA ? ST_PA : ST_PB) : 4096;
+    static_assert(2 * ST_STAGE + 128 * 8 + 3 * 1024 + 2 * 4096 <= ST_LDS, "spare LDS for the idle waves' stores");
+
+    // Row lists: the list entries of the NEXT request are fetched one request ahead and BEFORE this request's data
+    // loads (vector memory completes in order: waiting for the entries then leaves the data loads in flight); they stay
+    // raw registers until they are used -- a select right behind the load would wait for everything just requested.
+    int raw[4] = {0, 0, 0, 0};
+    auto fetch_rows = [&](int kt, int (&t)[4]) {
+        if constexpr (LIST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kbeg + kt * ST_KT + 4 * kq + r;
+                t[r] = ((gbl_i32_ptr)xidx)[k < kend ? k : 0];
+            }
+        }
+    };
+    auto request = [&](int kt, f32x4 (&v)[4]) {  // K-tile kt of this thread's block; rows past kend give zeros
+        int nxt[4] = {0, 0, 0, 0};
+        fetch_rows(kt + 1, nxt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kbeg + kt * ST_KT + 4 * kq + r;
+            const bool ok = loader && k < kend;
+            int row = k;
+            if constexpr (LIST) {
+                row = raw[r];
+                asm volatile("" : "+v"(row));
+            }
+            // (always issued, from a valid address, and kept RAW: park() zeroes the rows past kend -- a select right
+            // behind the load would wait for it, i.e. for the whole memory latency, in every K-tile)
+            v[r] = *(gbl_f32x4_ptr)((gbl_f32_ptr)X + (ok ? (size_t)row * ldx + col : 0));
+        }
+        if constexpr (LIST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[r] = nxt[r];
+        }
+    };
+    // split the 4 x 4 block of K-tile kt, one 8-B piece per row and plane
+    auto park = [&](int stage, const f32x4 (&v)[4], int kt) {
+        unsigned char* d = lds + stage * sstage + soff;
+        bool live[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) live[r] = kbeg + kt * ST_KT + 4 * kq + r < kend;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // the four k of row c as one vector: v_cvt_pk_bf16_f32 rounds a PAIR and leaves it packed the way the
+            // image wants it (5.5 VALU instructions per element; element-wise conversion + byte permutes cost 8.5,
+            // and this kernel is bound by instruction issue, not by the matrix cores)
+            f32x4 t;
+            t.x = live[0] ? v[0][c] : 0.f; t.y = live[1] ? v[1][c] : 0.f; t.z = live[2] ? v[2][c] : 0.f; t.w = live[3] ? v[3][c] : 0.f;
+            const bf16x4 h = __builtin_convertvector(t, bf16x4);
+            const f32x4 e = t - sw_unpack_bf16x4(h);
+            const bf16x4 m = __builtin_convertvector(e, bf16x4);
+            const bf16x4 l = __builtin_convertvector(e - sw_unpack_bf16x4(m), bf16x4);
+            *reinterpret_cast<bf16x4*>(d + c * cstep) = h;
+            *reinterpret_cast<bf16x4*>(d + c * cstep + pstep) = m;
+            *reinterpret_cast<bf16x4*>(d + c * cstep + 2 * pstep) = l;
+        }
+    };
+
+    // ---- fragments: row = 32-row block + li, k = 8 lh .. 8 lh + 7 = k-quads 2 lh, 2 lh + 1
+    int fa[2], fb[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int ra = wm * 64 + x * 32 + li, rb = wn * 64 + x * 32 + li;
+        fa[x] = ((2 * lh * 4 + (ra & 3)) * ST_QA + (ra >> 2)) * 8;
+        fb[x] = ST_A_BYTES + ((2 * lh * 4 + (rb & 3)) * ST_QB + (rb >> 2)) * 8;
+    }
+    auto frag = [&](const unsigned char* q, int kqstep) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + kqstep);
+        return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    };
+    auto compute = [&](int stage) {
+        const unsigned char* st = lds + stage * ST_STAGE;
+        bf16x8 a[3], b[2][3];  // (one row block of A at a time: 36 fragment registers, not 48)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[y][pl] = frag(st + fb[y] + pl * ST_PB, 4 * ST_QB * 8);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = frag(st + fa[x] + pl * ST_PA, 4 * ST_QA * 8);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {  // corrections smallest first; the leading product on its own
+                cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[y][0], cor[x][y], 0, 0, 0);
+                cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][2], cor[x][y], 0, 0, 0);
+                cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][1], cor[x][y], 0, 0, 0);
+                cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][0], cor[x][y], 0, 0, 0);
+                cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][1], cor[x][y], 0, 0, 0);
+                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][0], acc[x][y], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- K loop: K-tile t lives in register set t & 1 from two iterations before it is parked, in LDS stage t & 1
+    //      from the iteration before it is multiplied
+    f32x4 v0[4], v1[4];
+    fetch_rows(0, raw);
+    request(0, v0);
+    request(1, v1);
+    park(0, v0, 0);
+    request(2, v0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+        compute(0);
+        park(1, v1, kt + 1);
+        request(kt + 3, v1);
+        __syncthreads();
+        compute(1);
+        park(0, v0, kt + 2);
+        request(kt + 4, v0);
+        __syncthreads();
+    }
+    int cur = 0;
+    if (kt + 1 < nkt) {
+        compute(0);
+        park(1, v1, kt + 1);
+        __syncthreads();
+        cur = 1;
+    }
+    compute(cur);  // (one copy for both stages: the accumulators of the two ways into it meet in the same registers)
+    __syncthreads();
+
+    // ---- epilogue: the C tile staged in LDS, then 16-B pieces of whole rows (thread -> column quad c4, rows rw + 8 i)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] += cor[x][y];
+    float* cst = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cst[(wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ST_LDE + wn * 64 + y * 32 + li] = acc[x][y][r];
+    __syncthreads();
+    const int epi = p.epi;
+    const int c4 = tid & 63, rw = tid >> 6;
+    float* cbase = g.C + (size_t)m0 * p.ldc + n0 + c4 * 4;
+    if (epi & EPI_ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = rw + 8 * i;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(cst + lr * ST_LDE + c4 * 4);
+            float* cp = cbase + (size_t)lr * p.ldc;
+            sw_atomic_add(cp, v.x); sw_atomic_add(cp + 1, v.y); sw_atomic_add(cp + 2, v.z); sw_atomic_add(cp + 3, v.w);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+        f32x4 old[4];
+        if (epi & EPI_ADDC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) old[i] = *(gbl_f32x4_ptr)(gbl_f32_ptr)(cbase + (size_t)(rw + 8 * (i0 + i)) * p.ldc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lr = rw + 8 * (i0 + i);
+            f32x4 v = *reinterpret_cast<const f32x4*>(cst + lr * ST_LDE + c4 * 4);
+            if (epi & EPI_ADDC) v += old[i];
+            sw_gstore4(cbase + (size_t)lr * p.ldc, v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+bool split_tn_fits(const GemmDesc& d) {
+    return d.layout == GEMM_TN && d.M % ST_BM == 0 && d.N % ST_BN == 0 && d.K >= 1 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+           d.ldc % 4 == 0 && (d.epi == EPI_ATOMIC || d.epi == EPI_ADDC || d.epi == 0) && !d.unaligned &&
+           !(d.ragged & RAG_CIDX) && ((d.ragged & RAG_AIDX) != 0) == ((d.ragged & RAG_BIDX) != 0);
+}
+
+int launch_gemm_split_tn(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
+                         hipStream_t stream) {
+    if (d.M <= 0 || d.N <= 0 || ngroups <= 0) return SHIVAE_OK;
+    SV_REQUIRE(split_tn_fits(d), "gemm_split_tn: shape M=%d N=%d K=%d not supported", d.M, d.N, d.K);
+    SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "gemm_split_tn: %d groups need a device group table", ngroups);
+    SV_REQUIRE(d.splitk >= 1 && (d.splitk == 1 || d.epi == EPI_ATOMIC), "gemm_split_tn: split-K needs the atomic epilogue");
+    SV_REQUIRE(!d.ragged || groups_dev != nullptr, "gemm_split_tn: ragged launches take a device group table");
+    SV_REQUIRE(!d.ragged || d.epi == EPI_ATOMIC || d.epi == EPI_ADDC, "gemm_split_tn: a ragged launch accumulates into C");
+    if (!groups_dev)
+        SV_REQUIRE(sw_aligned16(g0.A) && sw_aligned16(g0.B) && sw_aligned16(g0.C), "gemm_split_tn: operands must be 16-B aligned");
+    else
+        SV_REQUIRE(d.c_aligned, "gemm_split_tn: group tables must be 16-B aligned");
+    SplitTnParams p;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.epi = d.epi; p.ragged = d.ragged;
+    p.splitk = d.splitk;
+    if (d.epi == EPI_ATOMIC) {
+        // the caller sized the K-splits for 128 x 128 tiles; these tiles are twice as large, so a launch of few groups
+        // would fill half the chip (atomic accumulation: any number of splits gives the same sum up to its order)
+        const long long tiles = (long long)(d.M / ST_BM) * (d.N / ST_BN) * ngroups;
+        while (tiles * p.splitk < 512 && d.K / (2 * p.splitk) >= 512) p.splitk *= 2;
+    }
+    p.kchunk = round_up(ceil_div(d.K, p.splitk), ST_KT);
+    p.ntx = d.N / ST_BN; p.nty = d.M / ST_BM; p.nz = ngroups * p.splitk;
+    p.groups = groups_dev; p.g0 = g0;
+    const long long units = (long long)p.nty * p.nz;
+    const long long nlin = (units + 7) / 8 * 8 * p.ntx;
+    SV_REQUIRE(nlin < (1ll << 31), "gemm_split_tn: grid too large");
+    prof_shape(d.M, d.N, d.K, ngroups);
+    prof_begin(PROF_SPLIT_TN, 2.0 * d.M * d.N * (double)d.K * ngroups, stream);
+    if (d.ragged & RAG_AIDX) hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
