@@ -651,31 +651,37 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
     // raw registers until they are used -- a select right behind the load would wait for everything just requested.
     int raw[4] = {0, 0, 0, 0};
     auto fetch_rows = [&](int kt, int (&t)[4]) {
-        if constexpr (LIST) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = kbeg + kt * ST_KT + 4 * kq + r;
-                t[r] = ((gbl_i32_ptr)xidx)[k < kend ? k : 0];
-            }
-        }
-    };
-    auto request = [&](int kt, f32x4 (&v)[4]) {  // K-tile kt of this thread's block; rows past kend give zeros
-        int nxt[4] = {0, 0, 0, 0};
-        fetch_rows(kt + 1, nxt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = kbeg + kt * ST_KT + 4 * kq + r;
-            const bool ok = loader && k < kend;
-            int row = k;
-            if constexpr (LIST) {
-                row = raw[r];
-                asm volatile("" : "+v"(row));
-            }
-            // (always issued, from a valid address, and kept RAW: park() zeroes the rows past kend -- a select right
-            // behind the load would wait for it, i.e. for the whole memory latency, in every K-tile)
-            v[r] = *(gbl_f32x4_ptr)((gbl_f32_ptr)X + (ok ? (size_t)row * ldx + col : 0));
+            t[r] = LIST ? ((gbl_i32_ptr)xidx)[k < kend ? k : 0] : 0;
         }
-        if constexpr (LIST) {
+    };
+    // K-tile kt of this thread's block, four 16-B loads, always issued and kept RAW (park() zeroes what is not live:
+    // a select right behind a load would wait for it, i.e. for the whole memory latency, in every K-tile).
+    // Without row lists: a wave-uniform slab base (scalar arithmetic) + four loop-invariant byte offsets -- no vector
+    // arithmetic at all (this kernel is bound by instruction issue).  The slab of the last K-tile is moved back so
+    // that it ends with the operand (slot (kq, r) then holds row slab_row + 4 kq + r, live iff it lies in
+    // [tile start, kend)); requests past the last K-tile repeat it.  No branch anywhere near a load.
+    unsigned voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) voff[r] = loader ? (unsigned)(((4 * kq + r) * ldx + col) * 4) : 0u;
+    auto slab_row = [&](int kt) { return min(kbeg + min(kt, nkt - 1) * ST_KT, p.K - ST_KT); };
+    auto request = [&](int kt, f32x4 (&v)[4]) {
+        if constexpr (!LIST) {
+            const unsigned char* slab = reinterpret_cast<const unsigned char*>(X) + (size_t)slab_row(kt) * ldx * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = *(gbl_f32x4_ptr)(gbl_void_ptr)(slab + voff[r]);
+        } else {
+            int nxt[4];
+            fetch_rows(kt + 1, nxt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kbeg + kt * ST_KT + 4 * kq + r;
+                int row = raw[r];
+                asm volatile("" : "+v"(row));
+                v[r] = *(gbl_f32x4_ptr)((gbl_f32_ptr)X + ((loader && k < kend) ? (size_t)row * ldx + col : 0));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) raw[r] = nxt[r];
         }
@@ -683,14 +689,16 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
     // split the 4 x 4 block of K-tile kt, one 8-B piece per row and plane
     auto park = [&](int stage, const f32x4 (&v)[4], int kt) {
         unsigned char* d = lds + stage * sstage + soff;
+        // slot r of this thread holds row first + r; live iff tile start <= row < kend
+        const int t0 = kbeg + kt * ST_KT;
+        const int first = (LIST ? t0 : slab_row(kt)) + 4 * kq;
         bool live[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) live[r] = kbeg + kt * ST_KT + 4 * kq + r < kend;
+        for (int r = 0; r < 4; ++r) live[r] = (unsigned)(first + r - t0) < (unsigned)(kend - t0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // the four k of row c as one vector: v_cvt_pk_bf16_f32 rounds a PAIR and leaves it packed the way the
-            // image wants it (5.5 VALU instructions per element; element-wise conversion + byte permutes cost 8.5,
-            // and this kernel is bound by instruction issue, not by the matrix cores)
+            // image wants it
             f32x4 t;
             t.x = live[0] ? v[0][c] : 0.f; t.y = live[1] ? v[1][c] : 0.f; t.z = live[2] ? v[2][c] : 0.f; t.w = live[3] ? v[3][c] : 0.f;
             const bf16x4 h = __builtin_convertvector(t, bf16x4);
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
 }
 
 bool split_tn_fits(const GemmDesc& d) {
-    return d.layout == GEMM_TN && d.M % ST_BM == 0 && d.N % ST_BN == 0 && d.K >= 1 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+    return d.layout == GEMM_TN && d.M % ST_BM == 0 && d.N % ST_BN == 0 && d.K >= ST_KT && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
            d.ldc % 4 == 0 && (d.epi == EPI_ATOMIC || d.epi == EPI_ADDC || d.epi == 0) && !d.unaligned &&
            !(d.ragged & RAG_CIDX) && ((d.ragged & RAG_AIDX) != 0) == ((d.ragged & RAG_BIDX) != 0);
 }
