@@ -591,7 +591,9 @@ struct SplitTnParams {
 };
 
 
-template <bool LIST>  // LIST: both operands' K rows come through row lists (the mask-aware decoder's layer 0)
+// LISTS: 0 no row lists; 1 both operands' K rows come through row lists (layer 0 of the mask-aware decoder, dense
+// input-gradient form); 2 only B's (compact form: the gradient operand is compact, the embedding is gathered)
+template <int LISTS>
 __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -637,7 +639,11 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
     const int rq = isA ? (lt & 31) : (lt & 63), kq = isA ? (lt >> 5) : ((lt >> 6) & 3);
     const float* X = isA ? g.A : g.B;
     const int ldx = isA ? p.lda : p.ldb;
-    const int* xidx = isA ? aidx : bidx;
+    // (LISTS == 2: the A loaders fetch B's list entries too and ignore them -- every wave issues the same sequence of
+    // vector memory operations, there is no branch round a load)
+    constexpr bool LIST = LISTS != 0;
+    const int* xidx = (LISTS == 2 || !isA) ? bidx : aidx;
+    const bool use_list = LISTS == 1 || (LISTS == 2 && !isA);
     const int col = (isA ? m0 : n0) + 4 * rq;
     // LDS byte offset of this block's piece for row c = 0: ((kq * 4 + c) * Q + rq) * 8; planes ST_PA / ST_PB apart
     const int Q = isA ? ST_QA : ST_QB;
@@ -680,6 +686,7 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
                 const int k = kbeg + kt * ST_KT + 4 * kq + r;
                 int row = raw[r];
                 asm volatile("" : "+v"(row));
+                row = use_list ? row : k;
                 v[r] = *(gbl_f32x4_ptr)((gbl_f32_ptr)X + ((loader && k < kend) ? (size_t)row * ldx + col : 0));
             }
 #pragma unroll
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
 bool split_tn_fits(const GemmDesc& d) {
     return d.layout == GEMM_TN && d.M % ST_BM == 0 && d.N % ST_BN == 0 && d.K >= ST_KT && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
            d.ldc % 4 == 0 && (d.epi == EPI_ATOMIC || d.epi == EPI_ADDC || d.epi == 0) && !d.unaligned &&
-           !(d.ragged & RAG_CIDX) && ((d.ragged & RAG_AIDX) != 0) == ((d.ragged & RAG_BIDX) != 0);
+           !(d.ragged & RAG_CIDX) && (!(d.ragged & RAG_AIDX) || (d.ragged & RAG_BIDX));
 }
 
 int launch_gemm_split_tn(const GemmDesc& d, const GemmGroup* groups_dev, int ngroups, const GemmGroup& g0,
@@ -855,8 +862,9 @@ int launch_gemm_split_tn(const GemmDesc& d, const GemmGroup* groups_dev, int ngr
     SV_REQUIRE(nlin < (1ll << 31), "gemm_split_tn: grid too large");
     prof_shape(d.M, d.N, d.K, ngroups);
     prof_begin(PROF_SPLIT_TN, 2.0 * d.M * d.N * (double)d.K * ngroups, stream);
-    if (d.ragged & RAG_AIDX) hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
+    if (d.ragged & RAG_AIDX) hipLaunchKernelGGL(gemm_split_tn_kernel<1>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
+    else if (d.ragged & RAG_BIDX) hipLaunchKernelGGL(gemm_split_tn_kernel<2>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_split_tn_kernel<0>, dim3((unsigned)nlin), dim3(ST_NT), 0, stream, p);
     prof_end(stream);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;

@@ -39,7 +39,11 @@ SHAPES = [(1, 1, 1), (5, 3, 7), (33, 65, 31), (128, 128, 32), (130, 20, 23), (25
           (1000, 17, 260), (40, 513, 64), (300, 2, 256), (2, 300, 256),
           # 16-B aligned 128x128-tile cases: LDS-DMA staging (TN / NN) with a K range that ends inside a K-tile,
           # a K shorter than one tile, whole tiles only
-          (132, 260, 100), (128, 132, 4), (200, 136, 333), (256, 256, 96)]
+          (132, 260, 100), (128, 132, 4), (200, 136, 333), (256, 256, 96),
+          # M % 128 == 0, N % 256 == 0: in split mode the TN layout takes gemm_split_tn_kernel (128 x 256 x 16 tiles) --
+          # one K-tile exactly, one row more, K ranges that end inside a K-tile (the last slab is moved back), an odd
+          # number of K-tiles, several row / column tiles
+          (128, 256, 16), (128, 256, 17), (128, 256, 33), (256, 512, 1000), (128, 512, 47), (384, 256, 2049)]
 
 
 @pytest.mark.parametrize("M,Nn,K", SHAPES)
@@ -75,6 +79,15 @@ def test_gemm_epilogues_and_splitk():
     np.testing.assert_allclose(out, np.maximum(base + bias + C0, 0) * (aux > 0), rtol=1e-5, atol=1e-4)
     out = _gemm(2, np.ascontiguousarray(A.T), np.ascontiguousarray(B.T), C0, epi=N.EPI_ATOMIC, splitk=3, M=M, N_=Nn, K=K)
     np.testing.assert_allclose(out, base + C0, rtol=1e-5, atol=1e-4)
+    # the split-mode TN kernel's epilogues (M % 128 == 0, N % 256 == 0): split-K atomics, read-modify-write, plain store
+    M2, N2, K2 = 256, 256, 531
+    A2 = rng.standard_normal((K2, M2)).astype(np.float32)
+    B2 = rng.standard_normal((K2, N2)).astype(np.float32)
+    C2 = rng.standard_normal((M2, N2)).astype(np.float32)
+    base2 = A2.astype(np.float64).T @ B2.astype(np.float64)
+    for epi, sk, want in ((N.EPI_ATOMIC, 3, base2 + C2), (N.EPI_ATOMIC, 1, base2 + C2), (N.EPI_ADDC, 1, base2 + C2), (0, 1, base2)):
+        out = _gemm(2, A2, B2, C2, epi=epi, splitk=sk, M=M2, N_=N2, K=K2)
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=2e-4, err_msg="epi %d splitk %d" % (epi, sk))
     # strided views: leading dims larger than the extents
     Ap = np.zeros((M, K + 5), np.float32); Ap[:, :K] = A
     Bp = np.zeros((Nn, K + 3), np.float32); Bp[:, :K] = B

@@ -6,7 +6,7 @@ import json, sys
 fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 cfg, B, T, src = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 NAMES = {"gemm_split_nt_kernel<128x256, pre-split W>": ["shivae::gemm_split_nt_kernel"],
-         "gemm_split_tn_kernel<128x256x16>": ["void shivae::gemm_split_tn_kernel<false>", "void shivae::gemm_split_tn_kernel<true>"],
+         "gemm_split_tn_kernel<128x256x16>": ["void shivae::gemm_split_tn_kernel<false>", "void shivae::gemm_split_tn_kernel<true>", "void shivae::gemm_split_tn_kernel<0>", "void shivae::gemm_split_tn_kernel<1>", "void shivae::gemm_split_tn_kernel<2>"],
          "gemm_kernel<NT,256x32>": ["void shivae::gemm_kernel<true, true, true, 4, 1, 2, 1, 4, false, false, false>"],
          "gemm_kernel<TN,256x32>": ["void shivae::gemm_kernel<false, false, true, 4, 1, 2, 1, 4, false, false, false>"]}
 path = "profiles/pmc_traffic.json"
