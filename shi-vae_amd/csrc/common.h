@@ -136,7 +136,7 @@ struct HeadGroup {
 };
 bool head_kernels_fit(int H, int nout, int ldin, int ldp);
 int launch_heads(bool bwd, const HeadGroup* groups_dev, int ngroups, int nout, int H, int ldin, int ldp, int rows,
-                 bool use_cnt, bool use_idx, hipStream_t stream);
+                 bool use_cnt, bool use_idx, hipStream_t stream, int live_rows = 0);
 
 struct AttrDesc;
 // Row lists of the mask-aware decoder: for every attribute d, idx[d*ld_idx + i] = i-th row (ascending) of the

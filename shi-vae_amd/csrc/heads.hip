@@ -265,7 +265,7 @@ static void launch_nout(int nout, bool bwd, const HeadParams& p, dim3 grid, hipS
 // rows: the dense row count (and the bound of every group's live count); use_cnt / use_idx: honour the groups'
 // device-side counts / row lists (mask-aware decoder)
 int launch_heads(bool bwd, const HeadGroup* groups_dev, int ngroups, int nout, int H, int ldin, int ldp, int rows,
-                 bool use_cnt, bool use_idx, hipStream_t stream) {
+                 bool use_cnt, bool use_idx, hipStream_t stream, int live_rows) {
     if (ngroups <= 0 || rows <= 0) return SHIVAE_OK;
     SV_REQUIRE(head_kernels_fit(H, nout, ldin, ldp), "heads: H=%d nout=%d ld=%d not supported by the streaming kernels", H, nout, ldin);
     SV_REQUIRE(ngroups <= 65535, "heads: too many groups");
@@ -274,8 +274,12 @@ int launch_heads(bool bwd, const HeadGroup* groups_dev, int ngroups, int nout, i
     p.use_idx = use_idx ? 1 : 0; p.use_cnt = use_cnt ? 1 : 0;
     // ~16 waves per CU over the whole launch, at least 64 rows per wave (amortises the weight registers and, in
     // the backward, the atomics at the end of a wave)
+    // With device-side row counts a group's live rows are its FIRST cnt rows, so the rows per wave are sized by the
+    // expected count (live_rows; 0 = all rows): sized by `rows`, a sparsely observed group keeps one or two waves busy
+    // and the launch is latency-bound (cfg5, 10 % observed: 1.6 waves per CU, 0.5 TB/s).
     const long long want_waves = 256ll * 16;
-    int rpw = (int)std::max<long long>(64, ((long long)rows * ngroups + want_waves - 1) / want_waves);
+    const int lrows = (use_cnt && live_rows > 0) ? std::min(rows, live_rows) : rows;
+    int rpw = (int)std::max<long long>(64, ((long long)lrows * ngroups + want_waves - 1) / want_waves);
     rpw = std::min(rpw, 1024);
     p.rows_per_wave = rpw;
     dim3 grid((unsigned)ceil_div(ceil_div(rows, rpw), 4), (unsigned)ngroups);

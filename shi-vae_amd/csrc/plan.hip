@@ -604,11 +604,14 @@ static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int
 }
 // streaming heads (heads.hip) with their profile record: algorithmic bytes = one read of the head input (+ one
 // write of its gradient in the backward) + the parameter columns
-static int heads(bool bwd, const HeadTable& t, int nout, int H, int ldin, int ldp, int rows, bool rag, hipStream_t s) {
+static int heads(bool bwd, const HeadTable& t, int nout, int H, int ldin, int ldp, int rows, bool rag, hipStream_t s,
+                 float obs_frac = -1.f) {
     if (t.n == 0) return SHIVAE_OK;
     if (rag && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, rows);
     prof_begin(bwd ? PROF_HEADS_BWD : PROF_HEADS_FWD, (double)t.n * rows * 4.0 * ((bwd ? 2.0 : 1.0) * H + nout), s);
-    SV_TRY(launch_heads(bwd, t.dev, t.n, nout, H, ldin, ldp, rows, rag, rag, s));
+    // (expected live rows per attribute: 1.25 x the observed fraction this plan measured, when it has one)
+    const int live = (rag && obs_frac >= 0.f) ? std::max(256, (int)(1.25f * obs_frac * rows) + 64) : 0;
+    SV_TRY(launch_heads(bwd, t.dev, t.n, nout, H, ldin, ldp, rows, rag, rag, s, live));
     prof_end(s);
     return SHIVAE_OK;
 }
@@ -825,7 +828,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             // keep finite leftovers -- zeros or older parameters -- which the likelihood kernel masks out)
             const int ldin = key < 0 ? ldA1 : ldHH;
             if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
-                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rc, rag, s));
+                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rc, rag, s, p->obs_frac));
                 continue;
             }
             SV_TRY(gemmg(NT, rc, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
@@ -845,7 +848,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
                 // one streaming pass: input gradient (ReLU-gated), weight and bias gradients, and the bias
                 // gradient of the layer that produced the head input (heads.hip)
-                SV_TRY(heads(true, p->h_out[key], nout, H, ldin, P, rc, rag, s));
+                SV_TRY(heads(true, p->h_out[key], nout, H, ldin, P, rc, rag, s, p->obs_frac));
                 continue;
             }
             // (ragged: the gradient rows of the observed entries are read through the row list; the dense column
