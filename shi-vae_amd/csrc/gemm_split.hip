@@ -568,19 +568,21 @@ int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngr
 //   two LDS stages of 42 KiB, ONE barrier per K-tile; a thread owns a 4(k) x 4(m) block of one operand: four 16-B
 //   global loads, requested two K-tiles ahead into one of two register sets, split in registers, stored as one 8-B
 //   piece per row and plane;
-//   LDS image: [plane][k-quad][row][4 bf16], row-linear (+16 B after every 32 rows): a fragment (8 k of one row) is
-//   two ds_read_b64, a thread's block two ds_write_b128 per plane, both conflict-free.
+//   LDS image (gemm.hip, row-contiguous operands): [plane][k-quad][row & 3][row >> 2 (+8)][4 bf16]: a fragment (8 k of
+//   one row) is two ds_read_b64, stores and reads are conflict-free.
 // The generic split kernel (gemm.hip: 128 x 128 x 32 on 4 waves, ONE LDS stage, two barriers per K-tile, two
 // workgroups per CU) splits every operand element once per 128 output columns and overlaps its split phase only with
 // the other workgroup of the CU: 143-156 TFLOP/s on the weight-gradient shapes of cfg3.
 // Takes: M % 128 == 0, N % 256 == 0, 16-B aligned rows; EPI_ATOMIC (split-K), EPI_ADDC or plain store; ragged K
 // (device-side count) and row lists for both operands (the mask-aware decoder).
 constexpr int ST_BM = 128, ST_BN = 256, ST_KT = 16, ST_NT = 512;
-// LDS image of one operand: [plane][k-quad][row][4 bf16 = 8 B], row-linear with 16 B of padding after every 32 rows:
-// a thread's four rows of a k-quad are 32 contiguous bytes (two ds_write_b128 per plane, lanes 8 apart land on
-// disjoint banks thanks to the padding), a fragment's 32 rows are 256 contiguous bytes (conflict-free ds_read_b64)
-constexpr int ST_KA = ST_BM * 8 + ST_BM / 32 * 16, ST_KB = ST_BN * 8 + ST_BN / 32 * 16;  // bytes per k-quad block
-constexpr int ST_PA = 4 * ST_KA, ST_PB = 4 * ST_KB;                                       // bytes per plane
+// LDS image of one operand: [plane][k-quad][row & 3][row >> 2 (+8 pad)][4 bf16 = 8 B]: a thread's four rows of a k-quad
+// go to the four (row & 3) blocks (one ds_write_b64 each, lanes = consecutive row quads = contiguous LDS), a fragment
+// (8 k of one row) is two ds_read_b64; the padded block stride puts the four blocks a read touches on disjoint banks.
+// (A row-linear image with two ds_write_b128 per plane and block -- half the LDS store instructions -- measured 3-4 %
+// slower on the shapes without row lists: 184 / 172 / 176 against 191 / 180 / 183 TFLOP/s, three alternating runs.)
+constexpr int ST_QA = ST_BM / 4 + 8, ST_QB = ST_BN / 4 + 8;          // row-quad strides of the (row & 3) blocks
+constexpr int ST_PA = 4 * 4 * ST_QA * 8, ST_PB = 4 * 4 * ST_QB * 8;  // bytes per plane (4 k-quads x 4 x Q x 8 B)
 constexpr int ST_A_BYTES = 3 * ST_PA, ST_B_BYTES = 3 * ST_PB;
 constexpr int ST_STAGE = ST_A_BYTES + ST_B_BYTES;                    // 43 008 B
 constexpr int ST_LDE = ST_BN + 4;
@@ -648,12 +650,12 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
     const int* xidx = (LISTS == 2 || !isA) ? bidx : aidx;
     const bool use_list = LISTS == 1 || (LISTS == 2 && !isA);
     const int col = (isA ? m0 : n0) + 4 * rq;
-    // LDS byte offset of this block's 32 bytes (rows 4 rq .. 4 rq + 3 of k-quad kq); planes ST_PA / ST_PB apart
-    const int soff = loader ? (isA ? 0 : ST_A_BYTES) + kq * (isA ? ST_KA : ST_KB) + rq * 32 + (rq >> 3) * 16
-                            : 2 * ST_STAGE + (tid - 384) * 32;
+    // LDS byte offset of this block's piece for row c = 0: ((kq * 4 + c) * Q + rq) * 8; planes ST_PA / ST_PB apart
+    const int Q = isA ? ST_QA : ST_QB;
+    const int soff = loader ? (isA ? 0 : ST_A_BYTES) + (kq * 4 * Q + rq) * 8 : 2 * ST_STAGE + (tid - 384) * 8;
     const int sstage = loader ? ST_STAGE : 0;                      // (the spare area is not staged)
-    const int pstep = loader ? (isA ? ST_PA : ST_PB) : 4096;
-    static_assert(2 * ST_STAGE + 128 * 32 + 2 * 4096 <= ST_LDS, "spare LDS for the idle waves' stores");
+    const int cstep = loader ? Q * 8 : 1024, pstep = loader ? (isA ? ST_PA : ST_PB) : 4096;
+    static_assert(2 * ST_STAGE + 128 * 8 + 3 * 1024 + 2 * 4096 <= ST_LDS, "spare LDS for the idle waves' stores");
 
     // Row lists: the list entries of the NEXT request are fetched one request ahead and BEFORE this request's data
     // loads (vector memory completes in order: waiting for the entries then leaves the data loads in flight); they stay
@@ -709,25 +711,20 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
         bool live[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) live[r] = (unsigned)(first + r - t0) < (unsigned)(kend - t0);
-        bf16x4 h[4], m[4], l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // the four k of row c as one vector: v_cvt_pk_bf16_f32 rounds a PAIR and leaves it packed the way the
             // image wants it
             f32x4 t;
             t.x = live[0] ? v[0][c] : 0.f; t.y = live[1] ? v[1][c] : 0.f; t.z = live[2] ? v[2][c] : 0.f; t.w = live[3] ? v[3][c] : 0.f;
-            h[c] = __builtin_convertvector(t, bf16x4);
-            const f32x4 e = t - sw_unpack_bf16x4(h[c]);
-            m[c] = __builtin_convertvector(e, bf16x4);
-            l[c] = __builtin_convertvector(e - sw_unpack_bf16x4(m[c]), bf16x4);
+            const bf16x4 h = __builtin_convertvector(t, bf16x4);
+            const f32x4 e = t - sw_unpack_bf16x4(h);
+            const bf16x4 m = __builtin_convertvector(e, bf16x4);
+            const bf16x4 l = __builtin_convertvector(e - sw_unpack_bf16x4(m), bf16x4);
+            *reinterpret_cast<bf16x4*>(d + c * cstep) = h;
+            *reinterpret_cast<bf16x4*>(d + c * cstep + pstep) = m;
+            *reinterpret_cast<bf16x4*>(d + c * cstep + 2 * pstep) = l;
         }
-        auto put = [&](unsigned char* q, const bf16x4 (&w)[4]) {  // rows c = 0..3: 32 contiguous bytes
-            *reinterpret_cast<bf16x8*>(q) = __builtin_shufflevector(w[0], w[1], 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<bf16x8*>(q + 16) = __builtin_shufflevector(w[2], w[3], 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        put(d, h);
-        put(d + pstep, m);
-        put(d + 2 * pstep, l);
     };
 
     // ---- fragments: row = 32-row block + li, k = 8 lh .. 8 lh + 7 = k-quads 2 lh, 2 lh + 1
@@ -735,8 +732,8 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int ra = wm * 64 + x * 32 + li, rb = wn * 64 + x * 32 + li;
-        fa[x] = 2 * lh * ST_KA + ra * 8 + (ra >> 5) * 16;
-        fb[x] = ST_A_BYTES + 2 * lh * ST_KB + rb * 8 + (rb >> 5) * 16;
+        fa[x] = ((2 * lh * 4 + (ra & 3)) * ST_QA + (ra >> 2)) * 8;
+        fb[x] = ST_A_BYTES + ((2 * lh * 4 + (rb & 3)) * ST_QB + (rb >> 2)) * 8;
     }
     auto frag = [&](const unsigned char* q, int kqstep) {
         const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + kqstep);
@@ -751,11 +748,11 @@ __global__ __launch_bounds__(ST_NT, 2) void gemm_split_tn_kernel(SplitTnParams p
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[y][pl] = frag(st + fb[y] + pl * ST_PB, ST_KB);
+            for (int pl = 0; pl < 3; ++pl) b[y][pl] = frag(st + fb[y] + pl * ST_PB, 4 * ST_QB * 8);
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = frag(st + fa[x] + pl * ST_PA, ST_KA);
+            for (int pl = 0; pl < 3; ++pl) a[pl] = frag(st + fa[x] + pl * ST_PA, 4 * ST_QA * 8);
 #pragma unroll
             for (int y = 0; y < 2; ++y) {  // corrections smallest first; the leading product on its own
                 cor[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[y][0], cor[x][y], 0, 0, 0);
