@@ -142,7 +142,10 @@ struct AttrDesc;
 // Row lists of the mask-aware decoder: for every attribute d, idx[d*ld_idx + i] = i-th row (ascending) of the
 // chunk in which the attribute is observed, cnt[d] = how many (base_missvae.py:271-274 picks the mask column).
 int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, int* idx,
-                         int ld_idx, int* cnt, hipStream_t stream);
+                         int ld_idx, int* cnt, hipStream_t stream, int* rank = nullptr);
+// out[row][0..E) = sum over the attributes d observed in the row of prod[rank[d][row]][d*blk .. +E)  (loss.hip)
+int launch_l0_gather(const int* rank, int D, int ld_rank, const float* prod, size_t ldp, int blk, int E, float* out,
+                     int ldo, int rows, hipStream_t stream);
 // Zero Y[row][d*blk .. (d+1)*blk) for every (row, attribute d) that is missing (what a ragged launch that stores
 // through a row list leaves untouched).
 int launch_zero_missing_blocks(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, float* Y,

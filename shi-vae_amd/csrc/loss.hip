@@ -665,12 +665,13 @@ int launch_reparam_bwd(const float* s, const float* ds, int ldk, int K, float te
 // wave, wave totals through LDS), which keeps every downstream summation order fixed by the data alone.
 __global__ __launch_bounds__(1024) void observed_rows_kernel(const AttrDesc* __restrict__ attrs, const uint8_t* __restrict__ mask,
                                                              int ldm, int rows, int* __restrict__ idx, int ld_idx,
-                                                             int* __restrict__ cnt) {
+                                                             int* __restrict__ cnt, int* __restrict__ rank) {
     __shared__ int wtot[16];
     const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const AttrDesc a = attrs[d];
     const int col = a.xoff + a.dim - 1;
     int* out = idx + (size_t)d * ld_idx;
+    int* rk = rank ? rank + (size_t)d * ld_idx : nullptr;  // the inverse: row -> its place in the list, or -1
     int run = 0;
     for (int base = 0; base < rows; base += 1024) {
         const int row = base + tid;
@@ -687,6 +688,7 @@ __global__ __launch_bounds__(1024) void observed_rows_kernel(const AttrDesc* __r
             tot += t;
         }
         if (obs) out[run + woff + before] = row;
+        if (rk && row < rows) rk[row] = obs ? run + woff + before : -1;
         run += tot;
         __syncthreads();
     }
@@ -694,10 +696,98 @@ __global__ __launch_bounds__(1024) void observed_rows_kernel(const AttrDesc* __r
 }
 
 int launch_observed_rows(const AttrDesc* attrs_dev, int D, const uint8_t* mask, int ldm, int rows, int* idx,
-                         int ld_idx, int* cnt, hipStream_t stream) {
+                         int ld_idx, int* cnt, hipStream_t stream, int* rank) {
     if (D <= 0) return SHIVAE_OK;
     SV_REQUIRE(rows >= 0 && rows <= ld_idx, "observed_rows: %d rows exceed the list stride %d", rows, ld_idx);
-    hipLaunchKernelGGL(observed_rows_kernel, dim3(D), dim3(1024), 0, stream, attrs_dev, mask, ldm, rows, idx, ld_idx, cnt);
+    hipLaunchKernelGGL(observed_rows_kernel, dim3(D), dim3(1024), 0, stream, attrs_dev, mask, ldm, rows, idx, ld_idx, cnt, rank);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+// ---------------------------------------------------------------- layer-0 input gradient: sum over attributes by gather
+// The compact layer-0 backward leaves one product row per OBSERVED (row, attribute) pair: prod[i][d*blk .. +E) for the
+// i-th observed row of attribute d.  The shared input's gradient is their sum over the attributes observed in a row
+// (decoders.py:127 feeds every attribute's network the same input).  One wave per chunk row walks the attributes in
+// ascending order -- 64 ranks per ballot, then one product row per set bit, two in flight -- and stores the sum once:
+// no atomics, no zero fill, and a summation order fixed by the data alone.
+template <int VEC>
+__global__ __launch_bounds__(512) void l0_gather_kernel(const int* __restrict__ rank, int D, int ld_rank,
+                                                        const float* __restrict__ prod, size_t ldp, int blk, int E,
+                                                        float* __restrict__ out, int ldo, int rows) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 8 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int PER = 4;  // pieces per lane: E <= 64 * PER * VEC
+    const int np = E / VEC;
+    float acc[PER][VEC];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[j][v] = 0.f;
+    auto fetch = [&](const float* src, float (&t)[PER][VEC]) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = lane + 64 * j;
+            if (q < np) {
+                if constexpr (VEC == 4) {
+                    const float4 x = reinterpret_cast<const float4*>(src)[q];
+                    t[j][0] = x.x; t[j][1] = x.y; t[j][2] = x.z; t[j][3] = x.w;
+                } else {
+                    t[j][0] = src[q];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) t[j][v] = 0.f;
+            }
+        }
+    };
+    auto add = [&](const float (&t)[PER][VEC]) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[j][v] += t[j][v];
+    };
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int rk = d0 + lane < D ? rank[(size_t)(d0 + lane) * ld_rank + row] : -1;
+        unsigned long long m = __ballot(rk >= 0);
+        while (m) {
+            const int b0 = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const bool two = m != 0;
+            const int b1 = two ? __ffsll((long long)m) - 1 : b0;
+            m &= m - 1;  // (0 & anything = 0 when there was no second bit)
+            const int i0 = __shfl(rk, b0), i1 = __shfl(rk, b1);
+            float t0[PER][VEC], t1[PER][VEC];
+            fetch(prod + (size_t)i0 * ldp + (size_t)(d0 + b0) * blk, t0);
+            if (two) fetch(prod + (size_t)i1 * ldp + (size_t)(d0 + b1) * blk, t1);
+            add(t0);
+            if (two) add(t1);
+        }
+    }
+    float* o = out + (size_t)row * ldo;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int q = lane + 64 * j;
+        if (q < np) {
+            if constexpr (VEC == 4)
+                reinterpret_cast<float4*>(o)[q] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            else
+                o[q] = acc[j][0];
+        }
+    }
+}
+
+int launch_l0_gather(const int* rank, int D, int ld_rank, const float* prod, size_t ldp, int blk, int E, float* out,
+                     int ldo, int rows, hipStream_t stream) {
+    if (rows <= 0) return SHIVAE_OK;
+    SV_REQUIRE(rows <= ld_rank && blk >= E, "l0_gather: %d rows exceed the rank stride %d, or block %d < E %d", rows, ld_rank, blk, E);
+    const bool v4 = E % 4 == 0 && blk % 4 == 0 && ldp % 4 == 0 && ldo % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(prod) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    SV_REQUIRE(v4 ? E <= 1024 : E <= 256, "l0_gather: E = %d too wide", E);
+    const dim3 grid(ceil_div(rows, 8)), block(512);
+    if (v4)
+        hipLaunchKernelGGL(l0_gather_kernel<4>, grid, block, 0, stream, rank, D, ld_rank, prod, ldp, blk, E, out, ldo, rows);
+    else
+        hipLaunchKernelGGL(l0_gather_kernel<1>, grid, block, 0, stream, rank, D, ld_rank, prod, ldp, blk, E, out, ldo, rows);
     SV_CHECK_HIP(hipGetLastError());
     return SHIVAE_OK;
 }

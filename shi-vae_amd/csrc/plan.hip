@@ -125,6 +125,9 @@ struct shivae_plan {
     // grouped-GEMM tables
     GroupTable b_l0_w, b_l0_wr;  // layer-0 weight gradient per attribute (ragged steps): main columns + the E % 128 remainder
     GroupTable b_l0_d, b_l0_dr;  // layer-0 input gradient per attribute over its observed rows, added into the chunk's rows
+    GroupTable b_l0_p, b_l0_pr;  // the same products stored per attribute for launch_l0_gather (l0_prod)
+    float* l0_prod = nullptr;    // [Rc][D * E4] over the dead a1 .. da2 buffers, or null when they are too small
+    int l0_gather = 1;           // SHIVAE_L0D_GATHER=0: the atomic form
     int demb_mode = 2;           // SHIVAE_DEMB: 0 "dense" (one GEMM over all attributes' column blocks), 1 "compact", 2 "auto"
     float obs_frac = -1.f;       // auto: observed fraction of the first row chunk this plan trained on (< 0: not seen yet)
     unsigned long long noise_seed = 0;  // seed of the scans' in-kernel noise (calls with u == eps == nullptr)
@@ -255,6 +258,7 @@ static void build_workspace(shivae_plan* p) {
     carve(p, "pbuf", Rc * p->P, cur);
     carve(p, "rowidx", D * Rc, cur);  // int: per attribute, the chunk's observed rows (launch_observed_rows)
     carve(p, "rowcnt", D, cur);       // int: how many
+    carve(p, "rowrank", D * Rc, cur);  // int: the inverse of rowidx (row -> place in the attribute's list, or -1)
     carve(p, "wpack", p->wpack_floats, cur);
     // K-contiguous (transposed) copies of the decoder weights for the input-gradient GEMMs
     carve(p, "wt0", (size_t)p->E * D * 2 * H, cur);
@@ -383,7 +387,8 @@ static int build_tables(shivae_plan* p) {
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     const float* embc = p->wsf("embc");
     std::vector<GemmGroup> fl0, fl1, fl2, fh0, wl0, wl0r, dl0, dl0r, wl1, dl1, wl2, dl2, wh0, dh0;
-    std::vector<GemmGroup> fl0i, fl1i, fl2i, fh0i, dl0i, dl1i, dl2i, dh0i;  // B = pre-split weight image
+    std::vector<GemmGroup> fl0i, fl1i, fl2i, fh0i, dl0i, dl1i, dl2i, dh0i, pl0i;  // B = pre-split weight image
+    std::vector<GemmGroup> pl0, pl0r;
     auto IMG = [&](const char* name, size_t idx, int N, int K) {
         return reinterpret_cast<const float*>(p->ws + p->ws_off.at(name) + idx * presplit_bytes(N, K));
     };
@@ -397,6 +402,10 @@ static int build_tables(shivae_plan* p) {
         // a few columns past a multiple of 128 (E = 528) go to a skinny launch of their own, as in gemm1
         const int rem = p->E % 128;
         p->l0_nmain = (p->E > 128 && rem > 0 && rem <= 32) ? p->E - rem : p->E;
+        // Product rows of the compact layer-0 input gradient (launch_l0_gather): by then the layer-1/2 and head
+        // activations and their gradients (a1, a2, da1, da2: carved back to back) are dead for the chunk.
+        const size_t room = (p->ws_off.at("hh") - p->ws_off.at("a1")) / sizeof(float);
+        p->l0_prod = ((size_t)p->Rc * D * p->E4 <= room && p->E <= 1024) ? a1 : nullptr;
     }
     std::vector<int> all, bc;
     std::map<int, std::vector<GemmGroup>> fo, wo, dO;
@@ -426,15 +435,23 @@ static int build_tables(shivae_plan* p) {
         dl0.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d), dembc, nullptr, nullptr, nullptr, nullptr, nullptr, list));
         if (p->l0_nmain < p->E)
             dl0r.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, dembc + p->l0_nmain, nullptr, nullptr, nullptr, nullptr, nullptr, list));
+        if (p->l0_prod) {
+            float* pd0 = p->l0_prod + (size_t)d * p->E4;
+            pl0.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d), pd0, nullptr, nullptr, nullptr));
+            if (p->l0_nmain < p->E)
+                pl0r.push_back(G(da0d, PA(SHIVAE_P_DEC0_W, d) + p->l0_nmain, pd0 + p->l0_nmain, nullptr, nullptr, nullptr));
+        }
         fl1.push_back(G(a0d, PA(SHIVAE_P_DEC2_W, d), a1d, PA(SHIVAE_P_DEC2_B, d), nullptr, nullptr));
         fl2.push_back(G(a1d, PA(SHIVAE_P_DEC4_W, d), a2d, PA(SHIVAE_P_DEC4_B, d), nullptr, nullptr));
         twin(fl0i, fl0.back(), IMG("wi_f0", d, 2 * H, p->E));
         // compact layer-0 input gradient against attribute d's K range of the transposed stack's image (rows = E,
         // K-tiles d*2H/32 ...: the image is K-tile major, so a K range is a contiguous slab)
-        if ((2 * H) % 32 == 0)
-            twin(dl0i, dl0.back(), reinterpret_cast<const float*>(
-                                       reinterpret_cast<const char*>(IMG("wi_t0", 0, p->E, D * 2 * H)) +
-                                       (size_t)d * (2 * H / 32) * 3 * p->E * 64));
+        if ((2 * H) % 32 == 0) {
+            const float* slab = reinterpret_cast<const float*>(reinterpret_cast<const char*>(IMG("wi_t0", 0, p->E, D * 2 * H)) +
+                                                               (size_t)d * (2 * H / 32) * 3 * p->E * 64);
+            twin(dl0i, dl0.back(), slab);
+            if (p->l0_prod) twin(pl0i, pl0.back(), slab);
+        }
         twin(fl1i, fl1.back(), IMG("wi_f2", d, H, 2 * H));
         twin(fl2i, fl2.back(), IMG("wi_f4", d, H, H));
         wl2.push_back(G(da2d, a1d, GA(SHIVAE_P_DEC4_W, d), nullptr, nullptr, nullptr));
@@ -480,6 +497,10 @@ static int build_tables(shivae_plan* p) {
     SV_TRY(make_table(p, fl0, p->f_l0, all));
     SV_TRY(make_table(p, wl0, p->b_l0_w, all)); SV_TRY(make_table(p, wl0r, p->b_l0_wr, all));
     SV_TRY(make_table(p, dl0, p->b_l0_d, all)); SV_TRY(make_table(p, dl0r, p->b_l0_dr, all));
+    if (p->l0_prod) {
+        SV_TRY(make_table(p, pl0, p->b_l0_p, all)); SV_TRY(make_table(p, pl0r, p->b_l0_pr, all));
+        SV_TRY(upload(p, pl0i, &p->b_l0_p.dev_img));
+    }
     SV_TRY(make_table(p, fl1, p->f_l1, all)); SV_TRY(make_table(p, fl2, p->f_l2, all)); SV_TRY(make_table(p, fh0, p->f_h0, bc));
     SV_TRY(make_table(p, wl1, p->b_l1_w, all)); SV_TRY(make_table(p, dl1, p->b_l1_d, all));
     SV_TRY(make_table(p, wl2, p->b_l2_w, all)); SV_TRY(make_table(p, dl2, p->b_l2_d, all));
@@ -782,6 +803,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
     const int rcnt = rag ? RAG_CNT : 0;
     int* rowidx = reinterpret_cast<int*>(p->wsf("rowidx"));
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
+    int* rowrank = reinterpret_cast<int*>(p->wsf("rowrank"));
     for (int r0 = 0; r0 < R; r0 += p->Rc) {
         const int rc = std::min(p->Rc, R - r0);
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
@@ -789,7 +811,8 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             // Mask-aware decoder: attribute d's network only runs on the rows in which d is observed (their
             // likelihood terms are the only ones in the loss, base_missvae.py:271-285).  Activations of group d
             // are stored compactly -- row i of its column block = its i-th observed row of the chunk.
-            SV_TRY(launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s));
+            SV_TRY(launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s,
+                                        p->l0_prod && p->l0_gather ? rowrank : nullptr));
             g_chunk_cnt_host = nullptr;
             if (prof_on() && p->cnt_host) {
                 // (a ring of 4 steps' worth of chunks: a profile session longer than that re-uses slots, and its
@@ -889,7 +912,19 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                          EPI_ATOMIC, s));
         }
-        if (cd) {
+        if (cd && p->l0_prod && p->l0_gather) {
+            // Compact form without atomics: each attribute's product rows are stored where the dead layer-1/2 buffers
+            // were (plain stores), then one pass sums, per chunk row, the rows of the attributes observed in it.
+            const int nm = p->l0_nmain, ldp = D * E4;
+            static const bool l0d_img = [] { const char* f = getenv("SHIVAE_L0D_IMG"); return !f || atoi(f) != 0; }();
+            GemmDesc probe{NT, rc, nm, 2 * H, ldA0, 0, ldp, 0, 0, 1, 0, 1, RAG_CNT, E};
+            if (split && l0d_img && p->b_l0_p.dev_img && split_nt_fits(probe))
+                SV_TRY(gemmg(NT, rc, nm, 2 * H, ldA0, 0, ldp, 0, 0, p->b_l0_p, s, RAG_CNT, false, E));
+            else
+                SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_p, s, RAG_CNT));
+            if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_pr, s, RAG_CNT));
+            SV_TRY(launch_l0_gather(rowrank, D, p->Rc, p->l0_prod, (size_t)ldp, E4, E, dembc, E4, rc, s));
+        } else if (cd) {
             const int nm = p->l0_nmain;
             SV_CHECK_HIP(hipMemsetAsync(dembc, 0, (size_t)rc * E4 * sizeof(float), s));
             // (split mode: as an NT launch against the attribute's K range of the transposed stack's weight image)
@@ -1097,7 +1132,7 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         build_pack_plan(p, wj, bj, false);
     }
     // decoder row chunk: bytes per row of chunk-local activations
-    const double per_row = 4.0 * ((double)p->D * p->H * 8 + (double)std::max(p->nbc, 1) * p->H * 2 + p->P + p->D + 2.0 * p->E4 +
+    const double per_row = 4.0 * ((double)p->D * p->H * 8 + (double)std::max(p->nbc, 1) * p->H * 2 + p->P + 2.0 * p->D + 2.0 * p->E4 +
                                   2.0 * p->Hp + 2.0 * p->Zp);
     int rc = cfg->chunk_rows;
     if (rc <= 0) {
@@ -1112,6 +1147,8 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
         const char* hm = getenv("SHIVAE_HEADS");
         p->stream_heads = !(hm && strcmp(hm, "gemm") == 0);
         const char* dm = getenv("SHIVAE_DEMB");
+        const char* lg = getenv("SHIVAE_L0D_GATHER");
+        p->l0_gather = lg ? atoi(lg) != 0 : 1;
         p->demb_mode = !dm ? 2 : strcmp(dm, "dense") == 0 ? 0 : strcmp(dm, "compact") == 0 ? 1 : 2;
     }
     build_workspace(p);

@@ -86,24 +86,31 @@ def test_mask_aware_equals_dense_at_full_width(setup, monkeypatch):
 
 
 def test_layer0_input_gradient_forms_agree(setup, monkeypatch):
-    """The decoder's layer-0 input gradient has a compact form (grouped GEMM over each attribute's observed rows, added
-    atomically into the chunk's rows) and a dense one (one GEMM with K = D*2H over zero-filled blocks): SHIVAE_DEMB
-    forces either; auto measures the observed fraction on the plan's first chunk and takes dense at 30 % missing."""
+    """The decoder's layer-0 input gradient has a compact form (grouped GEMM over each attribute's observed rows; the
+    products are summed over attributes by a gather per chunk row, or with SHIVAE_L0D_GATHER=0 added atomically into
+    the chunk's rows) and a dense one (one GEMM with K = D*2H over zero-filled blocks): SHIVAE_DEMB forces either;
+    auto measures the observed fraction on the plan's first chunk and takes dense at 30 % missing."""
     m, x, mask, u, eps = setup
     res = {}
-    for form in ("dense", "compact", "auto"):
-        monkeypatch.setenv("SHIVAE_DEMB", form)        # read at plan creation
+    for form in ("dense", "compact", "compact-atomic", "compact-split", "compact-atomic-split", "auto"):
+        monkeypatch.setenv("SHIVAE_DEMB", form.split("-")[0])        # read at plan creation
+        monkeypatch.setenv("SHIVAE_L0D_GATHER", "0" if "atomic" in form else "1")
         m._plans, m._active = {}, None
         try:
-            res[form] = _run(m, x, mask, u, eps)
+            res[form] = _run(m, x, mask, u, eps, split=int("split" in form))
             frac = m._active.observed_fraction
         finally:
             monkeypatch.delenv("SHIVAE_DEMB")
+            monkeypatch.delenv("SHIVAE_L0D_GATHER")
             m._plans, m._active = {}, None
         if form == "auto":
             assert abs(frac - float((~mask).float().mean())) < 0.02, frac   # (mask is per entry; 1/4 of the cat columns per attribute)
         else:
             assert frac < 0
-    for form in ("compact", "auto"):
+    for form in ("compact", "compact-atomic", "auto"):
         assert abs(res[form][0] - res["dense"][0]) <= 2e-6 * abs(res["dense"][0])
         assert _rel(res[form][1], res["dense"][1]) < 1e-4
+    # split arithmetic: the two sums over attributes see the same products
+    assert abs(res["compact-split"][0] - res["dense"][0]) <= 2e-6 * abs(res["dense"][0])
+    assert _rel(res["compact-split"][1], res["compact-atomic-split"][1]) < 1e-4
+    assert _rel(res["compact-split"][1], res["dense"][1]) < 3e-4

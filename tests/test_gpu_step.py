@@ -198,6 +198,21 @@ CASES = {
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_step_matches_oracle_on_seeded_inputs(name):
+    _check_case(name)
+
+
+@pytest.mark.parametrize("gather", ["1", "0"])
+@pytest.mark.parametrize("name", ["ragged_chunks", "cat_heavy_miss90", "single_timestep", "aligned_h32", "all_missing"])
+def test_compact_layer0_input_gradient_matches_oracle(name, gather, monkeypatch):
+    """SHIVAE_DEMB=compact forces the per-attribute form of the decoder's layer-0 input gradient at any observed
+    fraction; SHIVAE_L0D_GATHER picks between its two sums over attributes -- product rows stored and gathered per
+    chunk row (1, default) or added atomically (0).  E % 4 != 0 (single_timestep: E = 35) takes the gather's scalar form."""
+    monkeypatch.setenv("SHIVAE_DEMB", "compact")      # both read at plan creation
+    monkeypatch.setenv("SHIVAE_L0D_GATHER", gather)
+    _check_case(name)
+
+
+def _check_case(name):
     tl, T, B, H, Z, K, learn_std, miss, chunk = CASES[name]
     rng = np.random.default_rng(zlib.crc32(name.encode()))  # (str hashes change per process)
     P = so.init_params(tl, H, Z, K, learn_std, seed=1)
