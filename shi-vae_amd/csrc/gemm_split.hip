@@ -208,7 +208,7 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
     const int by = u % p.nty, bz = u / p.nty;
     const int gidx = bz / p.splitk, ks = bz % p.splitk;
     const GemmGroup g = sw_load_group(p.groups, p.g0, gidx);
-    const int m0 = by * SW_BM, n0 = bx * SW_BN;
+    const int n0 = bx * SW_BN;
     int Mrows = p.M;
     const int *aidx = nullptr, *cidx = nullptr;
     if (p.ragged) {
@@ -219,10 +219,11 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         if (p.ragged & RAG_AIDX) aidx = g.aidx;
         if (p.ragged & RAG_CIDX) cidx = g.cidx;
     }
-    if (m0 >= Mrows) return;
     const int kt0 = ks * p.kt_per_split, kt1 = min(p.KT, kt0 + p.kt_per_split);
     if (kt0 >= kt1) return;  // (split-K launches are atomic: nothing to add)
 
+    if (by * SW_BM >= Mrows) return;
+    const int m0 = by * SW_BM;
     f32x16 acc[2][2], cor[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -240,14 +241,25 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
     const int ar = tid >> 3, akq = tid & 7;
     const float* pa[2];
     bool aok[2];
+    {
+        int rsel[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = m0 + ar + 64 * i;
-        aok[i] = r < Mrows;
-        // (the list is read unconditionally -- a dummy word of A itself without one -- and selected afterwards)
-        const gbl_i32_ptr q = aidx ? (gbl_i32_ptr)aidx : (gbl_i32_ptr)g.A;
-        const int t = q[(aidx && aok[i]) ? r : 0];
-        pa[i] = g.A + (size_t)(aok[i] ? (aidx ? t : r) : 0) * p.lda + 4 * akq;
+        for (int i = 0; i < 2; ++i) {
+            const int r = m0 + ar + 64 * i;
+            aok[i] = r < Mrows;
+            rsel[i] = aok[i] ? r : 0;
+        }
+        if (aidx) {
+            // both list entries are requested before either is used (entry 0 for a dead row): written plainly, hipcc
+            // sinks each load into its row's `r < Mrows` branch with a vmcnt(0) behind it -- two memory round trips
+            // in a row at the head of every tile
+            int t0 = ((gbl_i32_ptr)aidx)[rsel[0]], t1 = ((gbl_i32_ptr)aidx)[rsel[1]];
+            asm volatile("" : "+v"(t0), "+v"(t1));
+            rsel[0] = aok[0] ? t0 : 0;
+            rsel[1] = aok[1] ? t1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pa[i] = g.A + (size_t)rsel[i] * p.lda + 4 * akq;
     }
     auto loadA = [&](int kt, f32x4 (&v)[2]) {
         const bool kok = kt * 32 + 4 * akq < p.K;  // K % 4 == 0: a float4 is all-valid or all-invalid
@@ -461,6 +473,11 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
         if (cidx) crow[i] = ((gbl_i32_ptr)cidx)[ok ? row : 0];
         if (epi & EPI_MASK) ax[i] = *(gbl_f32x4_ptr)((gbl_f32_ptr)g.aux + (ok ? (size_t)row * p.ldaux + col : 0));
     }
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi & EPI_BIAS) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bias4[c] = *((gbl_f32_ptr)g.bias + col + c);
+    }
     float* cst = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -470,11 +487,12 @@ __global__ __launch_bounds__(SW_NT, 2) void gemm_split_nt_kernel(SplitNtParams p
             for (int r = 0; r < 16; ++r)
                 cst[(wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SW_LDE + wn * 64 + y * 32 + li] = acc[x][y][r];
     __syncthreads();
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (epi & EPI_BIAS) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bias4[c] = *((gbl_f32_ptr)g.bias + col + c);
-    }
+    // Everything the pieces need from global memory has been requested above; ONE wait the compiler can see, here.
+    // Without it every round below starts with `s_waitcnt vmcnt(0)` -- the first use of that round's row number, which
+    // hipcc cannot prove landed because the previous rounds' waits sit inside their `row < Mrows` branches -- and
+    // that wait also covers the STORE of the round before: sixteen store round trips in a row, 8 of a K = 256 tile's
+    // 31 us.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), the other counters at their maxima (gfx9 encoding)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int lr = rw + 8 * i, row = m0 + lr;
@@ -547,6 +565,9 @@ int launch_gemm_split_nt(const GemmDesc& d, const GemmGroup* groups_dev, int ngr
     const long long units = (long long)p.nty * p.nz;
     const long long nlin = (units + 7) / 8 * 8 * p.ntx;
     SV_REQUIRE(nlin < (1ll << 31), "gemm_split_nt: grid too large");
+    // (Sizing the grid of a launch with device-side row counts by the EXPECTED live row tiles -- at cfg5 seven of
+    // eight tiles are dead -- measured 1.3 % of the cfg5 step: a dead workgroup leaves after two scalar loads.  Not
+    // worth a loop around this kernel's body, which cost 101 spilled registers when tried.)
     // (Persistent workgroups -- one per CU striding through the tiles, the next tile's first K-tile requested while
     // the last one of the current tile is multiplied -- were built and measured: same results, K = 256 tiles 109
     // against 137 TFLOP/s, long K equal.  With one workgroup per tile the dispatcher starts the next workgroup while

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
     const HeadGroup g = p.groups[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = p.use_cnt ? min(*g.cnt, p.rows) : p.rows;
-    const int r0 = wave * p.rows_per_wave, r1 = min(n, r0 + p.rows_per_wave);
-    if (r0 >= r1) return;
+    const int stride = gridDim.x * 4 * p.rows_per_wave;  // (the grid covers the EXPECTED live rows: launch_heads)
+    if (wave * p.rows_per_wave >= n) return;
     float4 w[NOUT][CB];
     bool live[CB];
 #pragma unroll
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
     float b[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) b[j] = g.b[j];
-    for (int i = r0; i < r1; ++i) {
+    for (int r0 = wave * p.rows_per_wave; r0 < n; r0 += stride)
+    for (int i = r0, r1 = min(n, r0 + p.rows_per_wave); i < r1; ++i) {
         float acc[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) acc[j] = 0.f;
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadParams p) {
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c = lane & 15, sub = lane >> 4;
     const int n = p.use_cnt ? min(*g.cnt, p.rows) : p.rows;
-    const int r0 = wave * p.rows_per_wave, r1 = min(n, r0 + p.rows_per_wave);
-    if (r0 >= r1) return;
+    const int stride = gridDim.x * 4 * p.rows_per_wave;
+    if (wave * p.rows_per_wave >= n) return;
     float4 w[NOUT][NI];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j)
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadParams p) {
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) b[j] = g.b[j];
     constexpr int U = 2;  // row quads per iteration
-    for (int base = r0; base < r1; base += 4 * U) {
+    for (int r0 = wave * p.rows_per_wave; r0 < n; r0 += stride)
+    for (int base = r0, r1 = min(n, r0 + p.rows_per_wave); base < r1; base += 4 * U) {
         float4 h[U][NI];
         int row[U];
         bool ok[U];
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
     const HeadGroup g = p.groups[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = p.use_cnt ? min(*g.cnt, p.rows) : p.rows;
-    const int r0 = wave * p.rows_per_wave, r1 = min(n, r0 + p.rows_per_wave);
-    if (r0 >= r1) return;
+    const int stride = gridDim.x * 4 * p.rows_per_wave;
+    if (wave * p.rows_per_wave >= n) return;
     float4 w[NOUT][CB], gw[NOUT][CB], cs[CB];
     bool live[CB];
 #pragma unroll
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadParams p) {
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) gb[j] = 0.f;
     constexpr int U = 4;  // rows in flight per wave (memory-level parallelism: 4 KB of loads + 4 KB of stores)
-    for (int base = r0; base < r1; base += U) {
+    for (int r0 = wave * p.rows_per_wave; r0 < n; r0 += stride)
+    for (int base = r0, r1 = min(n, r0 + p.rows_per_wave); base < r1; base += U) {
         float d[U][NOUT];
         float4 h[U][CB];
         bool ok[U];
@@ -282,7 +285,9 @@ int launch_heads(bool bwd, const HeadGroup* groups_dev, int ngroups, int nout, i
     int rpw = (int)std::max<long long>(64, ((long long)lrows * ngroups + want_waves - 1) / want_waves);
     rpw = std::min(rpw, 1024);
     p.rows_per_wave = rpw;
-    dim3 grid((unsigned)ceil_div(ceil_div(rows, rpw), 4), (unsigned)ngroups);
+    // (the grid covers lrows; the waves stride on through whatever a group has beyond that.  Sized by `rows`, a
+    // launch at 10 % observed spends most of its time dispatching workgroups that find nothing to do)
+    dim3 grid((unsigned)ceil_div(ceil_div(lrows, rpw), 4), (unsigned)ngroups);
     if (H <= 256) launch_nout<1>(nout, bwd, p, grid, stream);
     else launch_nout<2>(nout, bwd, p, grid, stream);
     SV_CHECK_HIP(hipGetLastError());

@@ -114,3 +114,23 @@ def test_layer0_input_gradient_forms_agree(setup, monkeypatch):
     assert abs(res["compact-split"][0] - res["dense"][0]) <= 2e-6 * abs(res["dense"][0])
     assert _rel(res["compact-split"][1], res["compact-atomic-split"][1]) < 1e-4
     assert _rel(res["compact-split"][1], res["dense"][1]) < 3e-4
+
+
+def test_underestimated_observed_fraction_only_costs_passes(setup):
+    """The streaming heads size their grids for the observed fraction the plan measured on its first chunk and walk
+    on, grid-strided, through whatever an attribute has beyond that.  Told a fraction far below the data's 70 %,
+    every wave takes several row blocks: same losses, same gradients."""
+    m, x, mask, u, eps = setup
+    m._plans, m._active = {}, None
+    try:
+        ref = {s: _run(m, x, mask, u, eps, split=s) for s in (0, 1)}
+        assert m._active.observed_fraction > 0.6
+        for frac in (0.02, 0.3):
+            N.check(N.lib().shivae_plan_set_observed_fraction(m._active.h, frac))
+            for s in (0, 1):
+                l, g = _run(m, x, mask, u, eps, split=s)
+                assert abs(l - ref[s][0]) <= 2e-6 * abs(ref[s][0]), (frac, s)
+                # (below 0.6 the layer-0 input gradient takes its compact form: summation order differs)
+                assert _rel(g, ref[s][1]) < 1e-4, (frac, s)
+    finally:
+        m._plans, m._active = {}, None
