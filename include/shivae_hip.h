@@ -144,6 +144,21 @@ float shivae_plan_observed_fraction(const shivae_plan* plan);
  * summed with fp32 atomics shared by the attributes: its summation order, hence its last bits, vary run to run. */
 int shivae_plan_set_observed_fraction(shivae_plan* plan, float f);
 
+/* Row capacity of the decoder's activation buffers, separately from the row chunk (default: equal).  A mask-aware
+ * training chunk (base_missvae.py:271-285: only observed entries have likelihood terms) keeps each attribute's
+ * activations for its observed rows only, so with most entries missing a chunk of chunk_rows rows fills a small part of
+ * buffers sized for chunk_rows dense rows -- and those buffers are nearly all of the chunk's memory.  rows < chunk_rows
+ * sizes them for `rows` rows per attribute: the same memory then carries a chunk several times larger (fewer, larger
+ * launches).  A training chunk in which some attribute is observed in more than `rows` rows is detected on the host
+ * before its launches go out (one host wait per chunk, only on plans with rows < chunk_rows) and run in pieces of
+ * `rows` rows instead (shivae_plan_overflow_chunks counts them); dense passes (forward only, imputation, generation)
+ * step `rows` rows at a time; such a plan always takes the compact form of the layer-0 input gradient.  Call before
+ * shivae_plan_bind (it changes shivae_plan_workspace_bytes); rows <= 0 restores the default.  No counterpart in the
+ * reference. */
+int shivae_plan_set_activation_rows(shivae_plan* plan, int rows);
+int shivae_plan_activation_rows(const shivae_plan* plan);
+long long shivae_plan_overflow_chunks(const shivae_plan* plan);
+
 size_t shivae_plan_workspace_bytes(const shivae_plan* plan);
 /* attach caller-owned device memory: workspace (>= workspace_bytes, 256-B aligned; it is zeroed
  * here, synchronously), the flat parameter buffer and the flat gradient buffer */

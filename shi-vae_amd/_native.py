@@ -29,7 +29,8 @@ EPI_BIAS, EPI_RELU, EPI_SOFTPLUS, EPI_ADDC, EPI_MASK, EPI_ATOMIC = 1, 2, 4, 8, 1
 # every symbol include/shivae_hip.h declares
 SYMBOLS = ["shivae_last_error", "shivae_version", "shivae_init", "shivae_plan_set_observed_fraction", "shivae_plan_create", "shivae_plan_destroy",
            "shivae_plan_num_params", "shivae_plan_param_info", "shivae_plan_x_dim", "shivae_plan_p_dim",
-           "shivae_plan_chunk_rows", "shivae_plan_observed_fraction", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
+           "shivae_plan_chunk_rows", "shivae_plan_set_activation_rows", "shivae_plan_activation_rows", "shivae_plan_overflow_chunks",
+           "shivae_plan_observed_fraction", "shivae_plan_workspace_bytes", "shivae_plan_bind", "shivae_elbo_step",
            "shivae_scan_fwd", "shivae_prior_kl", "shivae_decoder_nll", "shivae_scan_bwd", "shivae_loss_reduce",
            "shivae_set_gemm_split", "shivae_presplit_bytes", "shivae_presplit_weights", "shivae_gemm_nt_presplit", "shivae_sqnorm_noalloc", "shivae_comm_unique_id", "shivae_comm_init", "shivae_comm_destroy",
            "shivae_allreduce_grads",
@@ -71,8 +72,11 @@ def lib():
     L.shivae_plan_num_params.argtypes = [vp]
     L.shivae_plan_num_params.restype = i64
     L.shivae_plan_param_info.argtypes = [vp, ci, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)]
-    for f in ("shivae_plan_x_dim", "shivae_plan_p_dim", "shivae_plan_chunk_rows"):
+    for f in ("shivae_plan_x_dim", "shivae_plan_p_dim", "shivae_plan_chunk_rows", "shivae_plan_activation_rows"):
         getattr(L, f).argtypes = [vp]
+    L.shivae_plan_set_activation_rows.argtypes = [vp, ci]
+    L.shivae_plan_overflow_chunks.argtypes = [vp]
+    L.shivae_plan_overflow_chunks.restype = C.c_longlong
     L.shivae_plan_observed_fraction.argtypes = [vp]
     L.shivae_plan_observed_fraction.restype = cf
     L.shivae_plan_set_observed_fraction.argtypes = [vp, cf]
@@ -139,7 +143,7 @@ def stream():
 class Plan:
     """Owns one shivae_plan handle."""
 
-    def __init__(self, T, B, H, Z, K, attr_types, attr_nclass, learn_std, chunk_rows=0):
+    def __init__(self, T, B, H, Z, K, attr_types, attr_nclass, learn_std, chunk_rows=0, act_rows=0):
         n = len(attr_types)
         self._types = (C.c_int * n)(*attr_types)
         self._ncls = (C.c_int * n)(*attr_nclass)
@@ -148,6 +152,8 @@ class Plan:
         check(lib().shivae_plan_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.T, self.B = T, B
+        if act_rows:  # (rows of the decoder's activation buffers, when fewer than the chunk's: include/shivae_hip.h)
+            check(lib().shivae_plan_set_activation_rows(self.h, int(act_rows)))
 
     def __del__(self):
         try:
@@ -172,6 +178,14 @@ class Plan:
     @property
     def chunk_rows(self):
         return int(lib().shivae_plan_chunk_rows(self.h))
+
+    @property
+    def activation_rows(self):
+        return int(lib().shivae_plan_activation_rows(self.h))
+
+    @property
+    def overflow_chunks(self):
+        return int(lib().shivae_plan_overflow_chunks(self.h))
 
     @property
     def observed_fraction(self):

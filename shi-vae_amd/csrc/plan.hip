@@ -95,6 +95,15 @@ struct shivae_plan {
     int ldA0, ldA1, ldHH;  // leading dims of the decoder activations (+64 floats: no power-of-two row strides)
     int64_t R;
     int Rc;
+    // Row capacity of the decoder's ACTIVATION buffers (a0 .. dhh), <= Rc.  A mask-aware training chunk keeps attribute
+    // d's activations compactly (row i = its i-th observed row), so with most entries missing a chunk of Rc rows only
+    // ever fills the first max_d cnt_d rows of them: shivae_plan_set_activation_rows lets the chunk be several times
+    // larger than what the activations could hold densely.  Dense passes (forward only, imputation, generation,
+    // SHIVAE_COMPACT=0) step through the rows Ra at a time; a training chunk whose counts exceed Ra is re-run in
+    // pieces of Ra rows (n_overflow counts them).
+    int Ra;
+    int* cnt_guard = nullptr;  // pinned host copy of a chunk's counts for that check (allocated in shivae_plan_bind)
+    long long n_overflow = 0;
     int nbc;  // attributes with a hidden head layer (bin/cat)
     int nll_group = 64, nll_xspan = 0, nll_pspan = 0;  // likelihood kernel: attributes per staging step, widest spans
     std::vector<AttrDesc> attrs;
@@ -126,7 +135,7 @@ struct shivae_plan {
     GroupTable b_l0_w, b_l0_wr;  // layer-0 weight gradient per attribute (ragged steps): main columns + the E % 128 remainder
     GroupTable b_l0_d, b_l0_dr;  // layer-0 input gradient per attribute over its observed rows, added into the chunk's rows
     GroupTable b_l0_p, b_l0_pr;  // the same products stored per attribute for launch_l0_gather (l0_prod)
-    float* l0_prod = nullptr;    // [Rc][D * E4] over the dead a1 .. da2 buffers, or null when they are too small
+    float* l0_prod = nullptr;    // [Ra][D * E4] over the dead a1 .. da2 buffers, or null when they are too small
     int l0_gather = 1;           // SHIVAE_L0D_GATHER=0: the atomic form
     int demb_mode = 2;           // SHIVAE_DEMB: 0 "dense" (one GEMM over all attributes' column blocks), 1 "compact", 2 "auto"
     float obs_frac = -1.f;       // auto: observed fraction of the first row chunk this plan trained on (< 0: not seen yet)
@@ -250,11 +259,12 @@ static void build_workspace(shivae_plan* p) {
     // chunk-local
     carve(p, "embc", Rc * p->E4, cur);
     carve(p, "dembc", Rc * p->E4, cur);
-    carve(p, "a0", Rc * p->ldA0, cur);
-    carve(p, "da0", Rc * p->ldA0, cur);
-    for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Rc * p->ldA1, cur);
-    carve(p, "hh", Rc * p->ldHH, cur);
-    carve(p, "dhh", Rc * p->ldHH, cur);
+    const size_t Ra = (size_t)p->Ra;  // (activation rows: shivae_plan::Ra)
+    carve(p, "a0", Ra * p->ldA0, cur);
+    carve(p, "da0", Ra * p->ldA0, cur);
+    for (const char* n : {"a1", "a2", "da1", "da2"}) carve(p, n, Ra * p->ldA1, cur);
+    carve(p, "hh", Ra * p->ldHH, cur);
+    carve(p, "dhh", Ra * p->ldHH, cur);
     carve(p, "pbuf", Rc * p->P, cur);
     carve(p, "rowidx", D * Rc, cur);  // int: per attribute, the chunk's observed rows (launch_observed_rows)
     carve(p, "rowcnt", D, cur);       // int: how many
@@ -405,7 +415,7 @@ static int build_tables(shivae_plan* p) {
         // Product rows of the compact layer-0 input gradient (launch_l0_gather): by then the layer-1/2 and head
         // activations and their gradients (a1, a2, da1, da2: carved back to back) are dead for the chunk.
         const size_t room = (p->ws_off.at("hh") - p->ws_off.at("a1")) / sizeof(float);
-        p->l0_prod = ((size_t)p->Rc * D * p->E4 <= room && p->E <= 1024) ? a1 : nullptr;
+        p->l0_prod = ((size_t)p->Ra * D * p->E4 <= room && p->E <= 1024) ? a1 : nullptr;
     }
     std::vector<int> all, bc;
     std::map<int, std::vector<GemmGroup>> fo, wo, dO;
@@ -626,12 +636,13 @@ static int gemmg(int layout, int M, int N, int K, int lda, int ldb, int ldc, int
 // streaming heads (heads.hip) with their profile record: algorithmic bytes = one read of the head input (+ one
 // write of its gradient in the backward) + the parameter columns
 static int heads(bool bwd, const HeadTable& t, int nout, int H, int ldin, int ldp, int rows, bool rag, hipStream_t s,
-                 float obs_frac = -1.f) {
+                 float obs_frac = -1.f, int chunk_rows = 0) {
     if (t.n == 0) return SHIVAE_OK;
     if (rag && g_chunk_cnt_host) prof_ragged(&t.attr, g_chunk_cnt_host, rows);
     prof_begin(bwd ? PROF_HEADS_BWD : PROF_HEADS_FWD, (double)t.n * rows * 4.0 * ((bwd ? 2.0 : 1.0) * H + nout), s);
     // (expected live rows per attribute: 1.25 x the observed fraction this plan measured, when it has one)
-    const int live = (rag && obs_frac >= 0.f) ? std::max(256, (int)(1.25f * obs_frac * rows) + 64) : 0;
+    // (`rows` bounds a group's live count; with narrow activation buffers it is smaller than the chunk the fraction refers to)
+    const int live = (rag && obs_frac >= 0.f) ? std::max(256, (int)(1.25f * obs_frac * (chunk_rows > 0 ? chunk_rows : rows)) + 64) : 0;
     SV_TRY(launch_heads(bwd, t.dev, t.n, nout, H, ldin, ldp, rows, rag, rag, s, live));
     prof_end(s);
     return SHIVAE_OK;
@@ -804,15 +815,26 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
     int* rowidx = reinterpret_cast<int*>(p->wsf("rowidx"));
     int* rowcnt = reinterpret_cast<int*>(p->wsf("rowcnt"));
     int* rowrank = reinterpret_cast<int*>(p->wsf("rowrank"));
-    for (int r0 = 0; r0 < R; r0 += p->Rc) {
-        const int rc = std::min(p->Rc, R - r0);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);  // (no host wait inside a stream capture)
+    // Narrow activation buffers (Ra < Rc): only the compact forms fit them, and a chunk's counts are checked on the
+    // host before its launches go out.  Dense passes, and captures (no host wait), step Ra rows at a time.
+    const bool narrow = p->Ra < p->Rc;
+    const int step_rows = (rag && cap == hipStreamCaptureStatusNone) ? p->Rc : p->Ra;
+    auto observed_rows = [&](int r0, int rc) {
+        return launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s,
+                                    p->l0_prod && p->l0_gather ? rowrank : nullptr);
+    };
+    // one row chunk [r0, r0 + rc); lists_ready: observed_rows(r0, rc) has already run
+    auto chunk = [&](int r0, int rc, bool lists_ready) -> int {
+        // rr: row extent of everything that is indexed compactly (bounds every group's live count)
+        const int rr = rag ? std::min(rc, p->Ra) : rc;
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
         if (rag) {
             // Mask-aware decoder: attribute d's network only runs on the rows in which d is observed (their
             // likelihood terms are the only ones in the loss, base_missvae.py:271-285).  Activations of group d
             // are stored compactly -- row i of its column block = its i-th observed row of the chunk.
-            SV_TRY(launch_observed_rows(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, rowidx, p->Rc, rowcnt, s,
-                                        p->l0_prod && p->l0_gather ? rowrank : nullptr));
+            if (!lists_ready) SV_TRY(observed_rows(r0, rc));
             g_chunk_cnt_host = nullptr;
             if (prof_on() && p->cnt_host) {
                 // (a ring of 4 steps' worth of chunks: a profile session longer than that re-uses slots, and its
@@ -821,8 +843,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
                 SV_CHECK_HIP(hipMemcpyAsync(blk, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
                 g_chunk_cnt_host = blk;
             }
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(s, &cap);  // (no host wait inside a stream capture: the dense form is taken there)
+            // (no host wait inside a stream capture: the dense form is taken there)
             if (p->demb_mode == 2 && p->obs_frac < 0.f && cap == hipStreamCaptureStatusNone) {
                 // which form of the layer-0 input gradient pays depends on how much is observed (see below): measured
                 // once per plan, on its first training chunk (the only host wait in a step, and only in that one)
@@ -833,7 +854,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
                 for (int c : cnt) tot += c;
                 p->obs_frac = (float)(tot / ((double)D * rc));
             }
-            SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, RAG_CNT | RAG_AIDX));
+            SV_TRY(gemmg(NT, rr, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, RAG_CNT | RAG_AIDX));
         } else if (split && p->f_l0.dev_img && (2 * H) % 256 == 0 && E % 4 == 0 && rc > 64) {
             // dense rows, split mode: the same grouped launch over all rows (the weight images are per attribute)
             SV_TRY(gemmg(NT, rc, 2 * H, E, E4, E, ldA0, 0, EPI_BIAS | EPI_RELU, p->f_l0, s, 0));
@@ -842,19 +863,19 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
                          nullptr, 0, EPI_BIAS | EPI_RELU, s));
         }
-        SV_TRY(gemmg(NT, rc, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s, rcnt));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s, rcnt));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s, rcnt));
+        SV_TRY(gemmg(NT, rr, H, 2 * H, ldA0, 2 * H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l1, s, rcnt));
+        SV_TRY(gemmg(NT, rr, H, H, ldA1, H, ldA1, 0, EPI_BIAS | EPI_RELU, p->f_l2, s, rcnt));
+        SV_TRY(gemmg(NT, rr, H, H, ldA1, H, ldHH, 0, EPI_BIAS | EPI_RELU, p->f_h0, s, rcnt));
         for (auto& kv : p->f_out) {
             const int key = kv.first, nout = key < 0 ? -key : key;
             // (ragged: stored through the row list, so pbuf stays in chunk-row order; the rows of missing entries
             // keep finite leftovers -- zeros or older parameters -- which the likelihood kernel masks out)
             const int ldin = key < 0 ? ldA1 : ldHH;
             if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
-                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rc, rag, s, p->obs_frac));
+                SV_TRY(heads(false, p->h_out[key], nout, H, ldin, P, rr, rag, s, p->obs_frac, rc));
                 continue;
             }
-            SV_TRY(gemmg(NT, rc, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
+            SV_TRY(gemmg(NT, rr, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
         }
         if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
                                               hipMemcpyDeviceToDevice, s));
@@ -863,7 +884,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         SV_TRY(launch_heter_nll(p->attrs_dev, D, p->learn_std, x + (size_t)r0 * X, X, mask + (size_t)r0 * X, X, pbuf, P,
                                 grad ? pbuf : nullptr, P, rc, inv_batch, rowloss + (size_t)r0 * 6, X, P, p->nll_group, p->nll_xspan, p->nll_pspan, s));
         prof_end(s);
-        if (!grad) continue;
+        if (!grad) return SHIVAE_OK;
 
         // ---- decoder backward (pbuf now holds d nll / d head outputs) ----
         for (auto& kv : p->b_out_w) {
@@ -871,23 +892,23 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             if (p->stream_heads && head_kernels_fit(H, nout, ldin, P)) {
                 // one streaming pass: input gradient (ReLU-gated), weight and bias gradients, and the bias
                 // gradient of the layer that produced the head input (heads.hip)
-                SV_TRY(heads(true, p->h_out[key], nout, H, ldin, P, rc, rag, s, p->obs_frac));
+                SV_TRY(heads(true, p->h_out[key], nout, H, ldin, P, rr, rag, s, p->obs_frac, rc));
                 continue;
             }
             // (ragged: the gradient rows of the observed entries are read through the row list; the dense column
             // sums below are unaffected, the gradient is zero where the entry is missing)
-            SV_TRY(gemmg(TN, nout, H, rc, P, ldin, H, 0, EPI_ATOMIC, kv.second, s, rag ? RAG_CNT | RAG_AIDX : 0));
+            SV_TRY(gemmg(TN, nout, H, rr, P, ldin, H, 0, EPI_ATOMIC, kv.second, s, rag ? RAG_CNT | RAG_AIDX : 0));
             SV_TRY(colsumg(rc, nout, P, p->c_out[key], s));
             // d(head input) = dP * Wout, gated by the head input's ReLU; its column sums are the bias gradient
             // of the layer that produced the head input (EPI_COLSUM, here and in the trunk below)
-            SV_TRY(gemmg(NN, rc, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s,
+            SV_TRY(gemmg(NN, rr, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s,
                          rag ? RAG_CNT | RAG_AIDX : 0));
         }
-        SV_TRY(gemmg(TN, H, H, rc, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s, rcnt));
-        SV_TRY(gemmg(NT, rc, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s, rcnt));
-        SV_TRY(gemmg(TN, H, H, rc, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
-        SV_TRY(gemmg(NT, rc, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
-        SV_TRY(gemmg(TN, H, 2 * H, rc, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
+        SV_TRY(gemmg(TN, H, H, rr, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s, rcnt));
+        SV_TRY(gemmg(NT, rr, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s, rcnt));
+        SV_TRY(gemmg(TN, H, H, rr, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
+        SV_TRY(gemmg(NT, rr, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
+        SV_TRY(gemmg(TN, H, 2 * H, rr, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
         // Layer 0 backward, input gradient (the sum over attributes of decoders.py:127's shared input) in two forms.
         // "compact": da0 stays compact like the activations and one grouped GEMM over the observed rows of every
         // attribute ADDS its tiles into the chunk's rows: flops follow the observed fraction f, but every product is
@@ -895,19 +916,20 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         // cleared first) and one GEMM of K = D*2H sums over the attributes inside its K loop at 121 TFLOP/s,
         // multiplying the zeros of the missing blocks.  Measured step times (B=256, T=100): f = 0.72 (cfg3) 159.4 ms
         // compact / 157.1 dense; f = 0.11 (cfg5) 81.4 / 131.7.  auto: compact below f = 0.6.
-        const bool cd = rag && (p->demb_mode == 1 || (p->demb_mode == 2 && p->obs_frac >= 0.f && p->obs_frac < 0.6f));
+        // (narrow activation buffers have no room for da0 in chunk rows: compact whatever the fraction)
+        const bool cd = rag && (narrow || p->demb_mode == 1 || (p->demb_mode == 2 && p->obs_frac >= 0.f && p->obs_frac < 0.6f));
         if (rag && !cd) {
             if ((2 * H) % 4 == 0 && ldA0 % 4 == 0)
                 SV_TRY(launch_zero_missing_blocks(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, da0, ldA0, 2 * H, s));
             else
                 SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
         }
-        SV_TRY(gemmg(NT, rc, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s,
+        SV_TRY(gemmg(NT, rr, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s,
                      rag ? (cd ? RAG_CNT : RAG_CNT | RAG_CIDX) : 0));
         if (rag) {
             const int rl = cd ? RAG_CNT | RAG_BIDX : RAG_CNT | RAG_AIDX | RAG_BIDX, nm = p->l0_nmain;
-            SV_TRY(gemmg(TN, 2 * H, nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_w, s, rl));
-            if (nm < E) SV_TRY(gemmg(TN, 2 * H, E - nm, rc, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_wr, s, rl));
+            SV_TRY(gemmg(TN, 2 * H, nm, rr, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_w, s, rl));
+            if (nm < E) SV_TRY(gemmg(TN, 2 * H, E - nm, rr, ldA0, E4, E, 0, EPI_ATOMIC, p->b_l0_wr, s, rl));
         } else {
             SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                          EPI_ATOMIC, s));
@@ -917,24 +939,24 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             // were (plain stores), then one pass sums, per chunk row, the rows of the attributes observed in it.
             const int nm = p->l0_nmain, ldp = D * E4;
             static const bool l0d_img = [] { const char* f = getenv("SHIVAE_L0D_IMG"); return !f || atoi(f) != 0; }();
-            GemmDesc probe{NT, rc, nm, 2 * H, ldA0, 0, ldp, 0, 0, 1, 0, 1, RAG_CNT, E};
+            GemmDesc probe{NT, rr, nm, 2 * H, ldA0, 0, ldp, 0, 0, 1, 0, 1, RAG_CNT, E};
             if (split && l0d_img && p->b_l0_p.dev_img && split_nt_fits(probe))
-                SV_TRY(gemmg(NT, rc, nm, 2 * H, ldA0, 0, ldp, 0, 0, p->b_l0_p, s, RAG_CNT, false, E));
+                SV_TRY(gemmg(NT, rr, nm, 2 * H, ldA0, 0, ldp, 0, 0, p->b_l0_p, s, RAG_CNT, false, E));
             else
-                SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_p, s, RAG_CNT));
-            if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_pr, s, RAG_CNT));
+                SV_TRY(gemmg(NN, rr, nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_p, s, RAG_CNT));
+            if (nm < E) SV_TRY(gemmg(NN, rr, E - nm, 2 * H, ldA0, E, ldp, 0, 0, p->b_l0_pr, s, RAG_CNT));
             SV_TRY(launch_l0_gather(rowrank, D, p->Rc, p->l0_prod, (size_t)ldp, E4, E, dembc, E4, rc, s));
         } else if (cd) {
             const int nm = p->l0_nmain;
             SV_CHECK_HIP(hipMemsetAsync(dembc, 0, (size_t)rc * E4 * sizeof(float), s));
             // (split mode: as an NT launch against the attribute's K range of the transposed stack's weight image)
             static const bool l0d_img = [] { const char* f = getenv("SHIVAE_L0D_IMG"); return !f || atoi(f) != 0; }();
-            GemmDesc probe{NT, rc, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, 1, 0, 1, RAG_CNT | RAG_CIDX, E};
+            GemmDesc probe{NT, rr, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, 1, 0, 1, RAG_CNT | RAG_CIDX, E};
             if (split && l0d_img && p->b_l0_d.dev_img && split_nt_fits(probe))
-                SV_TRY(gemmg(NT, rc, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true, E));
+                SV_TRY(gemmg(NT, rr, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true, E));
             else
-                SV_TRY(gemmg(NN, rc, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
-            if (nm < E) SV_TRY(gemmg(NN, rc, E - nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_dr, s, RAG_CNT | RAG_CIDX, true));
+                SV_TRY(gemmg(NN, rr, nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_d, s, RAG_CNT | RAG_CIDX, true));
+            if (nm < E) SV_TRY(gemmg(NN, rr, E - nm, 2 * H, ldA0, E, E4, 0, EPI_ATOMIC, p->b_l0_dr, s, RAG_CNT | RAG_CIDX, true));
         } else {
             SV_TRY(gemm1(NT, rc, E, D * 2 * H, da0, ldA0, p->wsf("wt0"), D * 2 * H, dembc, E4, nullptr, nullptr, 0, 0, s,
                          p->wsf("wi_t0"), E));
@@ -945,6 +967,28 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
         // per-dispatch buffers do not survive thousands of launches enqueued ahead of the GPU -- DESIGN.md s.4)
         static const bool sync_chunks = [] { const char* f = getenv("SHIVAE_SYNC_CHUNKS"); return f && atoi(f) != 0; }();
         if (sync_chunks) SV_CHECK_HIP(hipStreamSynchronize(s));
+        return SHIVAE_OK;
+    };
+    for (int r0 = 0; r0 < R; r0 += step_rows) {
+        const int rc = std::min(step_rows, R - r0);
+        if (rag && rc > p->Ra) {
+            // more chunk rows than activation rows: the lists first, and the largest count checked on the host (one
+            // wait per chunk -- these chunks are several times the usual size, so it is a small fraction of one)
+            SV_TRY(observed_rows(r0, rc));
+            SV_CHECK_HIP(hipMemcpyAsync(p->cnt_guard, rowcnt, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
+            SV_CHECK_HIP(hipStreamSynchronize(s));
+            int mx = 0;
+            for (int d = 0; d < D; ++d) mx = std::max(mx, p->cnt_guard[d]);
+            if (mx > p->Ra) {
+                // an attribute is observed in more rows of this chunk than the buffers hold: pieces of Ra rows always fit
+                p->n_overflow++;
+                for (int q0 = r0; q0 < r0 + rc; q0 += p->Ra) SV_TRY(chunk(q0, std::min(p->Ra, r0 + rc - q0), false));
+                continue;
+            }
+            SV_TRY(chunk(r0, rc, true));
+        } else {
+            SV_TRY(chunk(r0, rc, false));
+        }
     }
     g_chunk_cnt_host = nullptr;
     return SHIVAE_OK;
@@ -1038,8 +1082,8 @@ static int generate(shivae_plan* p, const float* u, const float* eps, float temp
     SV_TRY(launch_scan_gen(sa, s));
     float *emb = p->wsf("emb"), *embc = p->wsf("embc"), *a0 = p->wsf("a0"), *pbuf = p->wsf("pbuf");
     const int ldA0 = p->ldA0, ldA1 = p->ldA1, ldHH = p->ldHH;
-    for (int r0 = 0; r0 < R; r0 += p->Rc) {
-        const int rc = std::min(p->Rc, R - r0);
+    for (int r0 = 0; r0 < R; r0 += p->Ra) {  // (dense rows: no more than the activation buffers hold)
+        const int rc = std::min(p->Ra, R - r0);
         SV_TRY(launch_compact_emb(emb + (size_t)r0 * Ep, Ep, Hp, Kp, H, K, embc, E4, rc, s));
         SV_TRY(gemm1(NT, rc, D * 2 * H, E, embc, E4, p->prm(g[SHIVAE_P_DEC0_W]), E, a0, ldA0, p->prm(g[SHIVAE_P_DEC0_B]),
                      nullptr, 0, EPI_BIAS | EPI_RELU, s));
@@ -1136,11 +1180,14 @@ int shivae_plan_create(const shivae_config* cfg, shivae_plan** out) {
                                   2.0 * p->Hp + 2.0 * p->Zp);
     int rc = cfg->chunk_rows;
     if (rc <= 0) {
-        const double budget = 40e9;  // bytes of chunk-local activations
+        // bytes of chunk-local activations (SHIVAE_CHUNK_BUDGET: tests of the host's chunk sizing on small models)
+        const char* cb = getenv("SHIVAE_CHUNK_BUDGET");
+        const double budget = cb && atof(cb) > 0 ? atof(cb) : 40e9;
         rc = (int)std::min<double>((double)p->R, std::max(256.0, budget / per_row));
         if (rc < p->R) rc = std::max(256, rc / 256 * 256);
     }
     p->Rc = (int)std::min<int64_t>(rc, p->R);
+    p->Ra = p->Rc;
     {
         const char* f = getenv("SHIVAE_COMPACT");
         p->compact = f ? atoi(f) != 0 : 1;
@@ -1164,6 +1211,10 @@ static void release_bound(shivae_plan* p) {
         (void)hipHostFree(p->cnt_host);
         p->cnt_host = nullptr;
     }
+    if (p->cnt_guard) {
+        (void)hipHostFree(p->cnt_guard);
+        p->cnt_guard = nullptr;
+    }
     p->cnt_slots = p->cnt_next = 0;
 }
 
@@ -1182,6 +1233,16 @@ int shivae_plan_set_observed_fraction(shivae_plan* p, float f) {
     SV_REQUIRE(p, "set_observed_fraction: null plan");
     SV_REQUIRE(f <= 1.f, "set_observed_fraction: %g is not a fraction", (double)f);
     p->obs_frac = f < 0.f ? -1.f : f;
+    return SHIVAE_OK;
+}
+int shivae_plan_activation_rows(const shivae_plan* p) { return p ? p->Ra : 0; }
+long long shivae_plan_overflow_chunks(const shivae_plan* p) { return p ? p->n_overflow : 0; }
+int shivae_plan_set_activation_rows(shivae_plan* p, int rows) {
+    SV_REQUIRE(p, "set_activation_rows: null plan");
+    SV_REQUIRE(!p->bound, "set_activation_rows: the plan is bound (the workspace layout is fixed by then); set it before shivae_plan_bind");
+    p->Ra = rows <= 0 ? p->Rc : std::min(std::max(rows, 16), p->Rc);
+    p->ws_off.clear();
+    build_workspace(p);
     return SHIVAE_OK;
 }
 size_t shivae_plan_workspace_bytes(const shivae_plan* p) { return p ? p->ws_bytes : 0; }
@@ -1224,6 +1285,7 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
         SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->cnt_host), (size_t)p->cnt_slots * p->D * sizeof(int),
                                    hipHostMallocDefault));
         p->cnt_next = 0;
+        SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->cnt_guard), (size_t)p->D * sizeof(int), hipHostMallocDefault));
     }
     SV_TRY(init_sqnorm_noalloc());  // (per-device set-up happens here, outside any stream capture)
     SV_TRY(upload(p, p->attrs, &p->attrs_dev));

@@ -83,6 +83,11 @@ class ShiVAE(nn.Module):
         self.check_nan = True       # base_missvae.py:223-228 (one host sync per forward)
         self.workspace_limit_bytes = int(float(os.environ.get("SHIVAE_WS_GB", "0")) * 1e9) or None
         self.chunk_rows = int(os.environ.get("SHIVAE_CHUNK_ROWS", "0"))
+        # rows of the decoder's activation buffers when fewer than the chunk's (shivae_plan_set_activation_rows):
+        # `act_rows` fixes them next to `chunk_rows`; otherwise _grow_chunk sizes them from the observed fraction of
+        # the first training batch of a shape when `narrow_activations` is on (SHIVAE_NARROW=0 turns it off)
+        self.act_rows = int(os.environ.get("SHIVAE_ACT_ROWS", "0"))
+        self.narrow_activations = os.environ.get("SHIVAE_NARROW", "1") != "0"
         # data parallel: start the all-reduce of the decoder's gradients (99 % of the buffer) as soon as the last
         # decoder row chunk is done, in buckets, while the reverse-time scan and the cell's weight gradients still
         # run.  Opt-in, because the caller then HAS to call allreduce_grads() (bench.py and Trainer do).
@@ -250,18 +255,22 @@ class ShiVAE(nn.Module):
                                       "is no CPU fallback" % self._flat.device)
         N.lib()
 
-    def _make_plan(self, T, B, chunk_rows=None):
+    def _make_plan(self, T, B, chunk_rows=None, act_rows=None):
         key = (T, B)
         if chunk_rows is not None:
             self._plans.pop(key, None)
         if key not in self._plans:
             self._plans[key] = N.Plan(T, B, self.h_dim, self.z_dim, self.s_dim, self._attr_types, self._attr_ncls,
-                                      self.learn_std, self.chunk_rows if chunk_rows is None else chunk_rows)
+                                      self.learn_std, self.chunk_rows if chunk_rows is None else chunk_rows,
+                                      (self.act_rows if chunk_rows is None else 0) if act_rows is None else act_rows)
         return self._plans[key]
 
-    def _grow_chunk(self, T, B):
+    def _grow_chunk(self, T, B, fmax=None):
         """Give the memory a micro-batch leaves unused to the decoder row chunk (fewer, larger launches).
-        Workspace is linear in the chunk rows, so two plans give the slope."""
+        Workspace is linear in the chunk rows, so two plans give the slope.  fmax: the largest observed fraction of
+        any attribute in the training batch, when known: a mask-aware chunk fills its activation buffers only that
+        far, so below 0.45 they are sized for 1.3 * fmax of the chunk's rows and the chunk grows by what that frees
+        (at 90 % missing: 5x the rows per launch; a chunk that does not fit after all is split by the library)."""
         if self.chunk_rows or (T, B) in self._chunk_done:
             return
         self._chunk_done.add((T, B))
@@ -274,6 +283,18 @@ class ShiVAE(nn.Module):
         ws1 = self._make_plan(T, B, chunk_rows=rc1).workspace_bytes
         per_row = max(1.0, (ws1 - ws0) / float(rc1 - rc0))
         rc = int(min(T * B, rc0 + 0.9 * (budget - ws0) / per_row)) // 128 * 128
+        frac = None if fmax is None or not self.narrow_activations else min(1.0, 1.3 * fmax + 0.01)
+        if frac is not None and frac <= 0.6 and rc < T * B:
+            # workspace = fixed + (per chunk row) * Rc + (per activation row) * Ra: a third plan separates the slopes
+            ra1 = max(16, int(frac * rc1))
+            ws1n = self._make_plan(T, B, chunk_rows=rc1, act_rows=ra1).workspace_bytes
+            per_act = max(0.0, (ws1 - ws1n) / float(rc1 - ra1))
+            per_narrow = max(1.0, per_row - per_act + frac * per_act)
+            rcn = int(min(T * B, 8 * max(rc, rc0), (rc0 * per_row + 0.9 * (budget - ws0)) / per_narrow)) // 128 * 128
+            ran = min(rcn, (int(frac * rcn) + 127) // 128 * 128)
+            if rcn > max(rc, rc0) and self._make_plan(T, B, chunk_rows=rcn, act_rows=ran).workspace_bytes <= budget:
+                self._active = None
+                return
         self._make_plan(T, B, chunk_rows=max(rc, rc0))
         self._active = None
 
@@ -401,7 +422,14 @@ class ShiVAE(nn.Module):
         flags = (0 if grad else N.STEP_FORWARD_ONLY) | (N.STEP_KEEP_PARAMS if keep_params else 0)
         bm = self.micro_batches(T, B)[0]
         self._slice_reserve = 0 if bm >= B else T * bm * (5 * self.x_dim + 4 * self.s_dim + 4 * self.z_dim)
-        self._grow_chunk(T, min(bm, B))
+        fmax = None
+        if (grad and not keep_params and self.narrow_activations and not self.chunk_rows
+                and (T, min(bm, B)) not in self._chunk_done):
+            # largest observed fraction of any attribute, from a sample of 16 time steps (sizes the activation buffers
+            # of the mask-aware decoder; an estimate is enough, the library checks every chunk's counts)
+            sub = mask[::max(1, T // 16)]
+            fmax = 1.0 - float(sub.sum(dim=(0, 1), dtype=torch.float32).min()) / float(sub.shape[0] * sub.shape[1])
+        self._grow_chunk(T, min(bm, B), fmax)
         graphed = self._graph_eligible(T, B, bm, collect)
         u, eps, seed = self._draw_noise(T, B, tensors=graphed)
         if graphed:

@@ -212,8 +212,79 @@ def test_compact_layer0_input_gradient_matches_oracle(name, gather, monkeypatch)
     _check_case(name)
 
 
-def _check_case(name):
-    tl, T, B, H, Z, K, learn_std, miss, chunk = CASES[name]
+@pytest.mark.parametrize("name,chunk,act,overflow", [
+    ("cat_heavy_miss90", 64, 32, False),   # ~6 observed rows per attribute and chunk of 64: fits 32 activation rows
+    ("cat_heavy_miss90", 152, 48, False),  # one chunk = the whole batch
+    ("aligned_h32", 128, 32, True),        # ~90 observed rows per chunk of 128: every chunk is re-run in pieces of 32
+    ("ragged_chunks", 100, 48, True),      # ~50 of 100 observed: some chunks fit, some do not
+])
+def test_narrow_activation_buffers_match_oracle(name, chunk, act, overflow):
+    """shivae_plan_set_activation_rows: activation buffers with fewer rows than the row chunk (what the mask-aware
+    decoder needs when most entries are missing).  Same oracle, same tolerances; a chunk whose counts exceed the
+    buffers is detected on the host and run in pieces."""
+    m = _check_case(name, chunk=chunk, act=act)
+    tl, T, B = CASES[name][:3]
+    plan = m._plans[(T, B)]
+    assert plan.chunk_rows == min(chunk, T * B) and plan.activation_rows == act
+    assert (plan.overflow_chunks > 0) == overflow, plan.overflow_chunks
+    # dense passes on the same plan (forward only: every row of every attribute) step through the rows `act` at a time
+    x, mask = _synth(np.random.default_rng(5), tl, T, B, CASES[name][7])
+    u, eps = np.random.default_rng(6).random((T, B, CASES[name][5])).astype(np.float32), \
+        np.random.default_rng(7).standard_normal((T, B, CASES[name][4])).astype(np.float32)
+    ref = shivae_amd.ShiVAE(*CASES[name][3:6], 1, types_list=tl, learn_std=CASES[name][6])
+    ref.load_state_dict(m.state_dict())
+    out = []
+    for mod in (m, ref):
+        mod.eval()
+        mod.set_noise(u, eps)
+        with torch.no_grad():
+            out.append(mod(torch.from_numpy(x), torch.from_numpy(mask), beta=1.0, temp=1.0))
+    for k in shivae_amd.LOSS_KEYS:
+        np.testing.assert_allclose(float(out[0][k]), float(out[1][k]), rtol=1e-5, atol=1e-5, err_msg=k)
+
+
+def test_chunk_grows_into_what_narrow_activations_free(monkeypatch):
+    """The host side of the same: with a workspace budget that holds two default chunks, a 90 %-missing training batch
+    gets activation buffers sized by its observed fraction and a chunk several times larger; losses and gradients
+    equal those of the plain layout (fp32 summation order aside)."""
+    monkeypatch.setenv("SHIVAE_CHUNK_BUDGET", "1")  # the library's default chunk: its minimum of 256 rows
+    tl = shivae_amd.utils.make_types_list(2, 2, 2, [4, 6], interleave=True)
+    T, B, H, Z, K = 40, 64, 64, 8, 4
+    rng = np.random.default_rng(17)
+    x, mask = _synth(rng, tl, T, B, 0.9)
+    u, eps = rng.random((T, B, K)).astype(np.float32), rng.standard_normal((T, B, Z)).astype(np.float32)
+    res, plans = {}, {}
+    for narrow in (False, True):
+        torch.manual_seed(3)
+        m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+        m.narrow_activations = narrow
+        p0 = m._make_plan(T, B)
+        assert p0.chunk_rows == 256
+        ws0 = p0.workspace_bytes
+        ws1 = m._make_plan(T, B, chunk_rows=512).workspace_bytes
+        m._plans.clear()
+        m.workspace_limit_bytes = ws0 + int((ws1 - ws0) * 1.2)  # room for ~2 default chunks
+        m.train()
+        m.set_noise(u, eps)
+        loss = m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.7, temp=2.0)
+        loss["n_elbo"].backward()
+        plans[narrow] = m._plans[(T, B)]
+        res[narrow] = ({k: float(loss[k].detach()) for k in shivae_amd.LOSS_KEYS},
+                       {k: p.grad.cpu().numpy().copy() for k, p in m.named_parameters()})
+    assert plans[False].activation_rows == plans[False].chunk_rows < T * B
+    assert plans[True].chunk_rows >= 2 * plans[False].chunk_rows, (plans[True].chunk_rows, plans[False].chunk_rows)
+    assert plans[True].activation_rows < plans[True].chunk_rows and plans[True].overflow_chunks == 0
+    assert plans[True].workspace_bytes <= ws0 + int((ws1 - ws0) * 1.2)
+    for k in shivae_amd.LOSS_KEYS:
+        np.testing.assert_allclose(res[True][0][k], res[False][0][k], rtol=1e-6, atol=1e-6, err_msg=k)
+    for k, gd in res[False][1].items():
+        err = np.abs(res[True][1][k] - gd).max() / max(np.abs(gd).max(), 1e-3)
+        assert err < 5e-5, (k, err)
+
+
+def _check_case(name, chunk=None, act=0):
+    tl, T, B, H, Z, K, learn_std, miss, chunk0 = CASES[name]
+    chunk = chunk0 if chunk is None else chunk
     rng = np.random.default_rng(zlib.crc32(name.encode()))  # (str hashes change per process)
     P = so.init_params(tl, H, Z, K, learn_std, seed=1)
     for k in P:
@@ -233,6 +304,7 @@ def _check_case(name):
     G = om.backward()
     m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=learn_std)
     m.chunk_rows = chunk
+    m.act_rows = act
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     m.train()
     m.set_noise(u, eps)
@@ -242,6 +314,7 @@ def _check_case(name):
     loss["n_elbo"].backward()
     bad = _golden.bad_grads(_grads(m), G)
     assert not bad, bad[:8]
+    return m
 
 
 def test_mask_aware_decoder_matches_dense(monkeypatch):
