@@ -487,7 +487,9 @@ class ShiVAE(nn.Module):
         if N.lib().shivae_profile_active():
             return False  # (the per-launch HIP events of the profiler cannot be recorded into a graph)
         plan = self._plans.get((T, B))
-        return plan is None or plan.chunk_rows >= T * B
+        # (one row chunk, and activation buffers that hold it: a narrow plan checks its counts on the host, which a
+        # capture cannot do)
+        return plan is None or (plan.chunk_rows >= T * B and plan.activation_rows >= plan.chunk_rows)
 
     def _step_graphed(self, x, mask, u, eps, beta, temp, inv_batch, flags):
         """The step through a HIP graph: the first call with a given (shape, scalars) runs eagerly (it binds the plan,
