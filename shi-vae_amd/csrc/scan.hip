@@ -116,6 +116,32 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) {
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
     return __builtin_nontemporal_load((const __attribute__((address_space(1))) f32x4*)p);
 }
+// Transcendentals of the recurrent chain.  They sit on the serial critical path of every timestep (the cell alone is
+// three sigmoids and two tanh per hidden unit, the Gumbel-softmax two logs, two exps and two divisions per class), and
+// the libm forms cost 12-40 DEPENDENT vector instructions each -- for a small model, whose step is one wave's latency
+// chain, about a third of the step.  The hardware-rate forms of cell_math.h (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp
+// each) cost 2-6.  tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): absolute error <= 2^-23 everywhere (relative
+// error grows only where |x| < 1e-3, i.e. where the value itself is below 1e-3).  -DSV_SCAN_LIBM restores libm.
+#ifdef SV_SCAN_LIBM
+__device__ __forceinline__ float sc_exp(float v) { return expf(v); }
+__device__ __forceinline__ float sc_rcp(float v) { return 1.f / v; }
+__device__ __forceinline__ float sc_sigmoid(float v) { return sv_sigmoid(v); }
+__device__ __forceinline__ float sc_tanh(float v) { return tanhf(v); }
+__device__ __forceinline__ float sc_softplus(float v) { return sv_softplus(v); }
+__device__ __forceinline__ float sc_softplus_grad_from_out(float sp) { return sv_softplus_grad_from_out(sp); }
+__device__ __forceinline__ float sc_gumbel(float u) { return sv_gumbel(u); }
+#else
+__device__ __forceinline__ float sc_exp(float v) { return sv_fexp(v); }
+__device__ __forceinline__ float sc_rcp(float v) { return sv_frcp(v); }
+__device__ __forceinline__ float sc_sigmoid(float v) { return sv_frcp(1.f + sv_fexp(-v)); }
+__device__ __forceinline__ float sc_tanh(float v) {
+    const float e = sv_fexp(-2.f * fabsf(v));  // in (0, 1]
+    return copysignf((1.f - e) * sv_frcp(1.f + e), v);
+}
+__device__ __forceinline__ float sc_softplus(float v) { return sv_softplus_fast(v); }
+__device__ __forceinline__ float sc_softplus_grad_from_out(float sp) { return sv_softplus_grad_from_out_fast(sp); }
+__device__ __forceinline__ float sc_gumbel(float u) { return -sv_flog(-sv_flog(u + 1e-20f) + 1e-20f); }
+#endif
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 __device__ __forceinline__ f32x4 gate4(f32x4 v, f32x4 a) { return f32x4{a[0] > 0.f ? v[0] : 0.f, a[1] > 0.f ? v[1] : 0.f, a[2] > 0.f ? v[2] : 0.f, a[3] > 0.f ? v[3] : 0.f}; }
 
@@ -248,11 +274,12 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 mma_acc<1>(lg, Wb + a.w.lg, HT, nt0, bufA, ln);
                 const f32x4 bl = ld4(Wb + a.w.b_lg + 4 * q);
                 float l[4], y[4], m1 = -INFINITY, m2 = -INFINITY;
+                const float inv_temp = sc_rcp(a.temp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool kv = 4 * q + r < a.K;
                     l[r] = sv_leaky(lg[0][r] + bl[r]);
-                    y[r] = (l[r] + sv_gumbel(u_pf[r])) / a.temp;
+                    y[r] = (l[r] + sc_gumbel(u_pf[r])) * inv_temp;
                     if (kv) { m1 = fmaxf(m1, l[r]); m2 = fmaxf(m2, y[r]); }
                 }
                 m1 = fmaxf(m1, __shfl_xor(m1, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
@@ -261,16 +288,17 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool kv = 4 * q + r < a.K;
-                    e1v[r] = kv ? expf(l[r] - m1) : 0.f;
-                    e2v[r] = kv ? expf(y[r] - m2) : 0.f;
+                    e1v[r] = kv ? sc_exp(l[r] - m1) : 0.f;
+                    e2v[r] = kv ? sc_exp(y[r] - m2) : 0.f;
                     s1 += e1v[r]; s2 += e2v[r];
                 }
                 s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
                 f32x4 pv, sv, lv4;
+                const float rs1 = sc_rcp(s1), rs2 = sc_rcp(s2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pv[r] = e1v[r] / s1; sv[r] = e2v[r] / s2;
+                    pv[r] = e1v[r] * rs1; sv[r] = e2v[r] * rs2;
                     lv4[r] = 4 * q + r < a.K ? l[r] : 0.f;
                 }
                 st4(sbuf + qidx(0, q, j), sv);
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
             if (zt != wid) ev = sv_eps4(a, row, zt * 4 + q, live);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                sd[r] = sv_softplus(sp[r]);
+                sd[r] = sc_softplus(sp[r]);
                 z[r] = ev[r] * sd[r] + mu[r];
             }
             st4(zbuf + qidx(zt, q, j), z);
@@ -414,12 +442,12 @@ __global__ __launch_bounds__(NTH) void scan_fwd_kernel(ScanArgs a) {
                 f32x4 gi, gf, gg, go, cn, hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    gi[r] = sv_sigmoid(g4[s][0][r]);
-                    gf[r] = sv_sigmoid(g4[s][1][r]);
-                    gg[r] = tanhf(g4[s][2][r]);
-                    go[r] = sv_sigmoid(g4[s][3][r]);
+                    gi[r] = sc_sigmoid(g4[s][0][r]);
+                    gf[r] = sc_sigmoid(g4[s][1][r]);
+                    gg[r] = sc_tanh(g4[s][2][r]);
+                    go[r] = sc_sigmoid(g4[s][3][r]);
                     cn[r] = gf[r] * creg[s][r] + gi[r] * gg[r];
-                    hv[r] = go[r] * tanhf(cn[r]);
+                    hv[r] = go[r] * sc_tanh(cn[r]);
                 }
                 creg[s] = cn;
                 st4(hn + qidx(ht, q, j), hv);
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
             const f32x4 ev = sv_eps4(a, row, zt * 4 + q, live);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                sd[r] = sv_softplus(sp[r]);
+                sd[r] = sc_softplus(sp[r]);
                 z[r] = ev[r] * sd[r] + mu[r];
             }
             st4(zbuf + qidx(zt, q, j), z);
@@ -575,10 +603,10 @@ __global__ __launch_bounds__(NTH) void scan_gen_kernel(ScanArgs a) {
                 f32x4 cn, hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float gi = sv_sigmoid(g4[s][0][r]), gf = sv_sigmoid(g4[s][1][r]);
-                    const float gg = tanhf(g4[s][2][r]), go = sv_sigmoid(g4[s][3][r]);
+                    const float gi = sc_sigmoid(g4[s][0][r]), gf = sc_sigmoid(g4[s][1][r]);
+                    const float gg = sc_tanh(g4[s][2][r]), go = sc_sigmoid(g4[s][3][r]);
                     cn[r] = gf * creg[s][r] + gi * gg;
-                    hv[r] = go * tanhf(cn[r]);
+                    hv[r] = go * sc_tanh(cn[r]);
                 }
                 creg[s] = cn;
                 st4(hn + qidx(ht, q, j), hv);
@@ -690,7 +718,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 f32x4 di, df, dg, dO, dc = dcreg[s];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float tc = tanhf(cn[r]);
+                    const float tc = sc_tanh(cn[r]);
                     const float dct = dc[r] + dh[r] * go[r] * (1.f - tc * tc);
                     di[r] = dct * gg[r] * gi[r] * (1.f - gi[r]);
                     df[r] = dct * cp[r] * gf[r] * (1.f - gf[r]);
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
             f32x4 dmu = acc[0] + xm, dsd = zero4;
             if (live) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dsd[r] = (acc[0][r] * ep[r] + xs[r]) * sv_softplus_grad_from_out(sd[r]);
+                for (int r = 0; r < 4; ++r) dsd[r] = (acc[0][r] * ep[r] + xs[r]) * sc_softplus_grad_from_out(sd[r]);
             } else dmu = acc[0];
             st4(dmub + qidx(zt, q, j), dmu);
             st4(dsdb + qidx(zt, q, j), dsd);
@@ -816,9 +844,10 @@ __global__ __launch_bounds__(NTH) void scan_bwd_kernel(ScanArgs a) {
                 dot += __shfl_xor(dot, 16);
                 dot += __shfl_xor(dot, 32);
                 f32x4 dl;
+                const float inv_temp = sc_rcp(a.temp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = k_s[r] * (ds[0][r] - dot) / a.temp + k_kl[r];
+                    float v = k_s[r] * (ds[0][r] - dot) * inv_temp + k_kl[r];
                     v *= k_lg[r] > 0.f ? 1.f : 0.01f;
                     dl[r] = (4 * q + r < a.K && live) ? v : 0.f;
                 }
