@@ -104,6 +104,13 @@ struct shivae_plan {
     int Ra;
     int* cnt_guard = nullptr;  // pinned host copy of a chunk's counts for that check (allocated in shivae_plan_bind)
     long long n_overflow = 0;
+    // Side streams for SMALL steps: the ~40 launches behind the reverse scan (the cell's weight and bias gradients, the
+    // phi_x backward) are independent of each other and, on a model of a few thousand rows, a few microseconds each --
+    // in one stream a chain of launch latencies.  Forked over the step's stream and these (events; the pattern a
+    // stream capture records as parallel branches), joined before the step goes on.  SHIVAE_FANOUT=0: one stream.
+    static constexpr int NSIDE = 3;
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
     int nbc;  // attributes with a hidden head layer (bin/cat)
     int nll_group = 64, nll_xspan = 0, nll_pspan = 0;  // likelihood kernel: attributes per staging step, widest spans
     std::vector<AttrDesc> attrs;
@@ -533,6 +540,64 @@ static int build_tables(shivae_plan* p) {
     return SHIVAE_OK;
 }
 
+// Zero fills and device-to-device copies inside a step.  Eager: hipMemsetAsync / hipMemcpyAsync.  Under stream capture
+// (or SHIVAE_ZERO_KERNEL=1): plain store kernels, so that a captured step consists of kernel nodes only.  Measured
+// reason (tools/graph_check_steps.py, ROCm 7.0): with the d_emb fill as a memset node, a replayed training step of a
+// small model now and then hands the reverse scan garbage of magnitude 1e10-1e14 (every gradient behind it is wrong,
+// the forward and its losses are not) -- the 77th replay of the cfg2 bench run, the 40th of another; the eager step on
+// the same parameters and noise is right, and 600 replays with the fill as a kernel node are all right.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ p4, size_t n4, float* __restrict__ tail, int ntail) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p4[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+static bool kernel_nodes_only(hipStream_t s) {
+    static const int force = [] { const char* f = getenv("SHIVAE_ZERO_KERNEL"); return f ? atoi(f) : -1; }();
+    if (force >= 0) return force != 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    return cap != hipStreamCaptureStatusNone;
+}
+__global__ __launch_bounds__(256) void zero2d_kernel(float* __restrict__ p, size_t ld, int cols, size_t rows) {
+    const size_t total = rows * (size_t)cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+// columns [0, cols) of `rows` rows of leading dimension ld
+static int zero2d_async(float* buf, size_t ld, int cols, size_t rows, hipStream_t s) {
+    if (cols <= 0 || rows == 0) return SHIVAE_OK;
+    if (!kernel_nodes_only(s)) {
+        SV_CHECK_HIP(hipMemset2DAsync(buf, ld * sizeof(float), 0, (size_t)cols * sizeof(float), rows, s));
+        return SHIVAE_OK;
+    }
+    const int grid = (int)std::min<size_t>((rows * (size_t)cols + 255) / 256, 4096);
+    hipLaunchKernelGGL(zero2d_kernel, dim3(grid), dim3(256), 0, s, buf, ld, cols, rows);
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+static int copy_async(float* dst, const float* src, size_t floats, hipStream_t s) {
+    if (floats == 0) return SHIVAE_OK;
+    if (!kernel_nodes_only(s) || floats >= ((size_t)1 << 31)) {
+        SV_CHECK_HIP(hipMemcpyAsync(dst, src, floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return SHIVAE_OK;
+    }
+    return launch_copy2d(src, (int)floats, 0, (int)floats, dst, (int)floats, 0, 1, s);
+}
+static int zero_async(float* buf, size_t floats, hipStream_t s) {
+    if (floats == 0) return SHIVAE_OK;
+    if (!kernel_nodes_only(s) || (reinterpret_cast<uintptr_t>(buf) & 15)) {
+        SV_CHECK_HIP(hipMemsetAsync(buf, 0, floats * sizeof(float), s));
+        return SHIVAE_OK;
+    }
+    const size_t n4 = floats / 4;
+    const int grid = (int)std::min<size_t>((n4 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(buf), n4, buf + n4 * 4, (int)(floats & 3));
+    SV_CHECK_HIP(hipGetLastError());
+    return SHIVAE_OK;
+}
+
+constexpr int64_t FANOUT_MAX_ROWS = 65536;  // steps of at most this many (t, b) rows fan their independent launches out (shivae_plan::side)
+
 // ------------------------------------------------------------ GEMM helpers
 static int splitk_for(int M, int N, int K, int groups) {
     const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * groups;
@@ -579,7 +644,7 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
         const float* B2 = layout == GEMM_NT ? B + (size_t)Nm * ldb : B + Nm;
         if (epi == 0 && K >= 4096) {
             // long-K skinny remainder: too few tiles to fill the chip -> zero the columns, split K, add atomically
-            SV_CHECK_HIP(hipMemset2DAsync(C + Nm, (size_t)ldc * sizeof(float), 0, (size_t)rem * sizeof(float), M, s));
+            SV_TRY(zero2d_async(C + Nm, (size_t)ldc, rem, (size_t)M, s));
             GemmDesc d{layout, M, rem, K, lda, ldb, ldc, 0, EPI_ATOMIC, std::min(32, ceil_div(K, 2048)), 0, 0};
             return launch_gemm(d, nullptr, 1, GemmGroup{A, B2, C + Nm, nullptr, nullptr}, s);
         }
@@ -602,7 +667,7 @@ static int gemm1(int layout, int M, int N, int K, const float* A, int lda, const
         static const int long_k_chunk = [] { const char* f = getenv("SHIVAE_LONGK_CHUNK"); return f ? atoi(f) : 16384; }();
         if (long_k_chunk > 0 && K >= 4 * long_k_chunk) sk = std::max(sk, std::min(64, K / long_k_chunk));
         if (sk > 1) {
-            SV_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+            SV_TRY(zero2d_async(C, (size_t)ldc, N, (size_t)M, s));
             d.epi = EPI_ATOMIC;
             d.splitk = sk;
         }
@@ -720,7 +785,7 @@ static int phase_prior_kl(shivae_plan* p, float beta, float inv_batch, bool grad
     const Tensor* g = p->glob;
     const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
-    if (grad) SV_CHECK_HIP(hipMemsetAsync(d_emb, 0, (size_t)R * Ep * sizeof(float), s));
+    if (grad) SV_TRY(zero_async(d_emb, (size_t)R * Ep, s));
 
     const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
                 *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
@@ -877,8 +942,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             }
             SV_TRY(gemmg(NT, rr, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s, rag ? RAG_CNT | RAG_CIDX : 0));
         }
-        if (keep) SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
-                                              hipMemcpyDeviceToDevice, s));
+        if (keep) SV_TRY(copy_async(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P, s));
         // algorithmic bytes per row: x (4X) + mask (X) + parameters (4P), + the gradient write (4P) in training
         prof_begin(PROF_NLL, (double)rc * (5.0 * X + 4.0 * P * (grad ? 2.0 : 1.0)), s);
         SV_TRY(launch_heter_nll(p->attrs_dev, D, p->learn_std, x + (size_t)r0 * X, X, mask + (size_t)r0 * X, X, pbuf, P,
@@ -922,7 +986,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             if ((2 * H) % 4 == 0 && ldA0 % 4 == 0)
                 SV_TRY(launch_zero_missing_blocks(p->attrs_dev, D, mask + (size_t)r0 * X, X, rc, da0, ldA0, 2 * H, s));
             else
-                SV_CHECK_HIP(hipMemsetAsync(da0, 0, (size_t)rc * ldA0 * sizeof(float), s));
+                SV_TRY(zero_async(da0, (size_t)rc * ldA0, s));
         }
         SV_TRY(gemmg(NT, rr, 2 * H, H, ldA1, H, ldA0, ldA0, EPI_MASK | EPI_COLSUM, p->b_l1_d, s,
                      rag ? (cd ? RAG_CNT : RAG_CNT | RAG_CIDX) : 0));
@@ -948,7 +1012,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(launch_l0_gather(rowrank, D, p->Rc, p->l0_prod, (size_t)ldp, E4, E, dembc, E4, rc, s));
         } else if (cd) {
             const int nm = p->l0_nmain;
-            SV_CHECK_HIP(hipMemsetAsync(dembc, 0, (size_t)rc * E4 * sizeof(float), s));
+            SV_TRY(zero_async(dembc, (size_t)rc * E4, s));
             // (split mode: as an NT launch against the attribute's K range of the transposed stack's weight image)
             static const bool l0d_img = [] { const char* f = getenv("SHIVAE_L0D_IMG"); return !f || atoi(f) != 0; }();
             GemmDesc probe{NT, rr, nm, 2 * H, ldA0, 0, E4, 0, EPI_ATOMIC, 1, 0, 1, RAG_CNT | RAG_CIDX, E};
@@ -1010,7 +1074,22 @@ static int phase_scan_bwd(shivae_plan* p, const float* x, const float* u, const 
         prof_begin(PROF_SCAN_BWD, scan_flops(p), s);
         SV_TRY(launch_scan(sa, true, s));
         prof_end(s);
-        // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics)
+        // 5. weight gradients of the cell, batched over all rows (K dim = rows, split-K + atomics).  Every launch from
+        //    here to the end of the phase only reads the records and writes a gradient tensor of its own (the phi_x
+        //    chain excepted, which stays on one stream): small steps deal them round the side streams.
+        static const bool fan_on = [] { const char* f = getenv("SHIVAE_FANOUT"); return !f || atoi(f) != 0; }();
+        const bool fan = fan_on && p->side[0] && p->R <= FANOUT_MAX_ROWS && !prof_on();
+        int turn = 0;
+        auto S = [&]() -> hipStream_t {
+            if (!fan) return s;
+            const int i = turn;
+            turn = (turn + 1) % (shivae_plan::NSIDE + 1);
+            return i == 0 ? s : p->side[i - 1];
+        };
+        if (fan) {
+            SV_CHECK_HIP(hipEventRecord(p->ev_fork, s));
+            for (int i = 0; i < shivae_plan::NSIDE; ++i) SV_CHECK_HIP(hipStreamWaitEvent(p->side[i], p->ev_fork, 0));
+        }
         const float *phiz = emb, *s_t = emb + Hp, *hprev = emb + Hp + Kp;
         float *d_gates = p->wsf("d_gates"), *d_phz = p->wsf("d_phiz_pre"), *d_mu = p->wsf("d_mu"),
               *d_sd = p->wsf("d_sd_pre"), *d_e2 = p->wsf("d_e2_pre"), *d_e1 = p->wsf("d_e1_pre"),
@@ -1018,39 +1097,46 @@ static int phase_scan_bwd(shivae_plan* p, const float* x, const float* u, const 
         for (int gt = 0; gt < 4; ++gt) {  // gate blocks are padded H -> Hp in the records
             const float* dg = d_gates + gt * Hp;
             SV_TRY(gemm1(TN, H, H, R, dg, 4 * Hp, phiz, Ep, p->grd(g[SHIVAE_P_RNN_WIH]) + (size_t)gt * H * H, H, nullptr,
-                         nullptr, 0, EPI_ATOMIC, s));
+                         nullptr, 0, EPI_ATOMIC, S()));
             SV_TRY(gemm1(TN, H, H, R, dg, 4 * Hp, hprev, Ep, p->grd(g[SHIVAE_P_RNN_WHH]) + (size_t)gt * H * H, H, nullptr,
-                         nullptr, 0, EPI_ATOMIC, s));
-            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BIH]) + gt * H, s));
-            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BHH]) + gt * H, s));
+                         nullptr, 0, EPI_ATOMIC, S()));
+            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BIH]) + gt * H, S()));
+            SV_TRY(colsum1(R, H, 4 * Hp, dg, p->grd(g[SHIVAE_P_RNN_BHH]) + gt * H, S()));
         }
-        SV_TRY(gemm1(TN, H, Z, R, d_phz, Hp, p->wsf("z"), Zp, p->grd(g[SHIVAE_P_PHIZ_W]), Z, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_phz, p->grd(g[SHIVAE_P_PHIZ_B]), s));
-        SV_TRY(gemm1(TN, Z, H, R, d_mu, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, Z, Zp, d_mu, p->grd(g[SHIVAE_P_ENCMEAN_B]), s));
-        SV_TRY(gemm1(TN, Z, H, R, d_sd, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, Z, Zp, d_sd, p->grd(g[SHIVAE_P_ENCSTD_B]), s));
-        SV_TRY(gemm1(TN, H, H, R, d_e2, Hp, p->wsf("e1"), Hp, p->grd(g[SHIVAE_P_E2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_e2, p->grd(g[SHIVAE_P_E2_B]), s));
+        SV_TRY(gemm1(TN, H, Z, R, d_phz, Hp, p->wsf("z"), Zp, p->grd(g[SHIVAE_P_PHIZ_W]), Z, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, H, Hp, d_phz, p->grd(g[SHIVAE_P_PHIZ_B]), S()));
+        SV_TRY(gemm1(TN, Z, H, R, d_mu, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, Z, Zp, d_mu, p->grd(g[SHIVAE_P_ENCMEAN_B]), S()));
+        SV_TRY(gemm1(TN, Z, H, R, d_sd, Zp, p->wsf("e2"), Hp, p->grd(g[SHIVAE_P_ENCSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, Z, Zp, d_sd, p->grd(g[SHIVAE_P_ENCSTD_B]), S()));
+        SV_TRY(gemm1(TN, H, H, R, d_e2, Hp, p->wsf("e1"), Hp, p->grd(g[SHIVAE_P_E2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, H, Hp, d_e2, p->grd(g[SHIVAE_P_E2_B]), S()));
         float* gE0 = p->grd(g[SHIVAE_P_E0_W]);
-        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, phx, Hp, gE0, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(gemm1(TN, H, K, R, d_e1, Hp, s_t, Ep, gE0 + H, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, hprev, Ep, gE0 + H + K, E, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_e1, p->grd(g[SHIVAE_P_E0_B]), s));
-        SV_TRY(gemm1(TN, K, H, R, d_lg, Kp, p->wsf("as"), Hp, p->grd(g[SHIVAE_P_XS2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, K, Kp, d_lg, p->grd(g[SHIVAE_P_XS2_B]), s));
+        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, phx, Hp, gE0, E, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(gemm1(TN, H, K, R, d_e1, Hp, s_t, Ep, gE0 + H, E, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(gemm1(TN, H, H, R, d_e1, Hp, hprev, Ep, gE0 + H + K, E, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, H, Hp, d_e1, p->grd(g[SHIVAE_P_E0_B]), S()));
+        SV_TRY(gemm1(TN, K, H, R, d_lg, Kp, p->wsf("as"), Hp, p->grd(g[SHIVAE_P_XS2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, K, Kp, d_lg, p->grd(g[SHIVAE_P_XS2_B]), S()));
         float* gXS0 = p->grd(g[SHIVAE_P_XS0_W]);
-        SV_TRY(gemm1(TN, H, X, R, d_as, Hp, x, X, gXS0, X + H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(gemm1(TN, H, H, R, d_as, Hp, hprev, Ep, gXS0 + X, X + H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_as, p->grd(g[SHIVAE_P_XS0_B]), s));
+        SV_TRY(gemm1(TN, H, X, R, d_as, Hp, x, X, gXS0, X + H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(gemm1(TN, H, H, R, d_as, Hp, hprev, Ep, gXS0 + X, X + H, nullptr, nullptr, 0, EPI_ATOMIC, S()));
+        SV_TRY(colsum1(R, H, Hp, d_as, p->grd(g[SHIVAE_P_XS0_B]), S()));
         // 6. phi_x backward (encoders.py:47-51)
         float *d_phx = p->wsf("d_phx_pre"), *d_p1 = p->wsf("d_p1_pre");
-        SV_TRY(gemm1(NN, R, H, H, d_e1, Hp, p->prm(g[SHIVAE_P_E0_W]), E, d_phx, Hp, nullptr, phx, Hp, EPI_MASK, s));
-        SV_TRY(gemm1(TN, H, H, R, d_phx, Hp, p1, Hp, p->grd(g[SHIVAE_P_PHIX2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_phx, p->grd(g[SHIVAE_P_PHIX2_B]), s));
-        SV_TRY(gemm1(NN, R, H, H, d_phx, Hp, p->prm(g[SHIVAE_P_PHIX2_W]), H, d_p1, Hp, nullptr, p1, Hp, EPI_MASK, s));
-        SV_TRY(gemm1(TN, H, X, R, d_p1, Hp, x, X, p->grd(g[SHIVAE_P_PHIX0_W]), X, nullptr, nullptr, 0, EPI_ATOMIC, s));
-        SV_TRY(colsum1(R, H, Hp, d_p1, p->grd(g[SHIVAE_P_PHIX0_B]), s));
+        const hipStream_t sc = S();
+        SV_TRY(gemm1(NN, R, H, H, d_e1, Hp, p->prm(g[SHIVAE_P_E0_W]), E, d_phx, Hp, nullptr, phx, Hp, EPI_MASK, sc));
+        SV_TRY(gemm1(TN, H, H, R, d_phx, Hp, p1, Hp, p->grd(g[SHIVAE_P_PHIX2_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, sc));
+        SV_TRY(colsum1(R, H, Hp, d_phx, p->grd(g[SHIVAE_P_PHIX2_B]), sc));
+        SV_TRY(gemm1(NN, R, H, H, d_phx, Hp, p->prm(g[SHIVAE_P_PHIX2_W]), H, d_p1, Hp, nullptr, p1, Hp, EPI_MASK, sc));
+        SV_TRY(gemm1(TN, H, X, R, d_p1, Hp, x, X, p->grd(g[SHIVAE_P_PHIX0_W]), X, nullptr, nullptr, 0, EPI_ATOMIC, sc));
+        SV_TRY(colsum1(R, H, Hp, d_p1, p->grd(g[SHIVAE_P_PHIX0_B]), sc));
+        if (fan) {  // join: the step's stream waits for every side stream
+            for (int i = 0; i < shivae_plan::NSIDE; ++i) {
+                SV_CHECK_HIP(hipEventRecord(p->ev_join[i], p->side[i]));
+                SV_CHECK_HIP(hipStreamWaitEvent(s, p->ev_join[i], 0));
+            }
+        }
     }
 
     return SHIVAE_OK;
@@ -1098,8 +1184,7 @@ static int generate(shivae_plan* p, const float* u, const float* eps, float temp
             }
             SV_TRY(gemmg(NT, rc, nout, H, ldin, H, P, 0, EPI_BIAS, kv.second, s));
         }
-        SV_CHECK_HIP(hipMemcpyAsync(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P * sizeof(float),
-                                    hipMemcpyDeviceToDevice, s));
+        SV_TRY(copy_async(p->wsf("pfull") + (size_t)r0 * P, pbuf, (size_t)rc * P, s));
     }
     p->last_flags = SHIVAE_STEP_FORWARD_ONLY | SHIVAE_STEP_KEEP_PARAMS;
     return SHIVAE_OK;
@@ -1216,6 +1301,11 @@ static void release_bound(shivae_plan* p) {
         p->cnt_guard = nullptr;
     }
     p->cnt_slots = p->cnt_next = 0;
+    for (int i = 0; i < shivae_plan::NSIDE; ++i) {
+        if (p->side[i]) { (void)hipStreamDestroy(p->side[i]); p->side[i] = nullptr; }
+        if (p->ev_join[i]) { (void)hipEventDestroy(p->ev_join[i]); p->ev_join[i] = nullptr; }
+    }
+    if (p->ev_fork) { (void)hipEventDestroy(p->ev_fork); p->ev_fork = nullptr; }
 }
 
 void shivae_plan_destroy(shivae_plan* plan) {
@@ -1287,6 +1377,13 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
         p->cnt_next = 0;
         SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->cnt_guard), (size_t)p->D * sizeof(int), hipHostMallocDefault));
     }
+    if (p->R <= FANOUT_MAX_ROWS) {  // (only steps small enough to use them get side streams)
+        SV_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < shivae_plan::NSIDE; ++i) {
+            SV_CHECK_HIP(hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking));
+            SV_CHECK_HIP(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming));
+        }
+    }
     SV_TRY(init_sqnorm_noalloc());  // (per-device set-up happens here, outside any stream capture)
     SV_TRY(upload(p, p->attrs, &p->attrs_dev));
     std::vector<PackJob> wj, bj;
@@ -1353,7 +1450,7 @@ int shivae_scan_bwd(shivae_plan* p, const float* x, const float* u, const float*
     // caller-supplied gradients replace the records the other phases accumulate (padding columns stay zero)
     if (d_emb) {
         float* de = p->wsf("d_emb");
-        SV_CHECK_HIP(hipMemsetAsync(de, 0, (size_t)R * Ep * sizeof(float), s));
+        SV_TRY(zero_async(de, (size_t)R * Ep, s));
         SV_TRY(launch_copy2d(d_emb, E, 0, H, de, Ep, 0, R, s));
         SV_TRY(launch_copy2d(d_emb, E, H, K, de, Ep, Hp, R, s));
         SV_TRY(launch_copy2d(d_emb, E, H + K, H, de, Ep, Hp + Kp, R, s));
@@ -1456,9 +1553,7 @@ int shivae_get_output(shivae_plan* p, int which, float* dst, shivae_stream strea
 int shivae_get_persum(shivae_plan* p, float* dst, shivae_stream stream) {
     SV_REQUIRE(p && dst, "get_persum: null argument");
     if (!p->bound) { set_error("get_persum: plan not bound"); return SHIVAE_ERR_UNBOUND; }
-    SV_CHECK_HIP(hipMemcpyAsync(dst, p->wsf("persum"), (size_t)p->B * 6 * sizeof(float), hipMemcpyDeviceToDevice,
-                                static_cast<hipStream_t>(stream)));
-    return SHIVAE_OK;
+    return copy_async(dst, p->wsf("persum"), (size_t)p->B * 6, static_cast<hipStream_t>(stream));
 }
 
 int shivae_heter_nll(shivae_plan* p, const float* x, const uint8_t* mask, const float* params, int ldp, float* dparams,

@@ -353,6 +353,43 @@ def test_mask_aware_decoder_matches_dense(monkeypatch):
         assert err < 5e-5, (k, err)
 
 
+def test_captured_training_run_matches_eager_stepwise():
+    """A training run of a small model through the captured (HIP-graph) step, every replay re-computed eagerly on the
+    same parameters and noise tensors.  Regression test: with the d_emb fill captured as a memset node the 77th replay
+    of exactly this run handed the reverse scan garbage (gradients of 1e14, losses unaffected) and the run went to
+    NaN two steps later; captured steps now consist of kernel nodes only (plan.hip zero_async)."""
+    from shivae_amd.synth import synth_batch
+    tl = shivae_amd.utils.make_types_list(35, 0, 0, [])
+    T, B, H, Z, K = 48, 64, 10, 35, 10
+    x, mask = synth_batch(tl, T, B, miss=0.3, seed=1234, device="cuda", chunk=B, seq0=0)
+    torch.manual_seed(0)
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+    m.check_nan = False
+    m.train()
+    opt = shivae_amd.FusedClipAdam(m, lr=5e-3, clip=0.5)
+    ref = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+    ref.use_graphs = False
+    ref.train()
+    for it in range(110):
+        before = m.flat_params.clone()
+        opt.zero_grad()
+        loss = m(x, mask, beta=1.0, temp=3.0)
+        loss["n_elbo"].backward()
+        g = m.flat_grads.clone()
+        u, eps = m._last.get("u"), m._last.get("eps")
+        if it >= 2:
+            assert len(m._graphs) == 1 and u is not None, "the step was not replayed from a graph"
+            ref.flat_params.copy_(before)
+            ref.zero_grad()
+            ref.set_noise(u, eps)
+            l2 = ref(x, mask, beta=1.0, temp=3.0)
+            l2["n_elbo"].backward()
+            np.testing.assert_allclose(float(loss["n_elbo"].detach()), float(l2["n_elbo"].detach()), rtol=1e-5, err_msg="step %d" % it)
+            err = float((g - ref.flat_grads).abs().max()) / float(ref.flat_grads.abs().max())
+            assert err < 1e-3, (it, err)
+        opt.step()
+
+
 def test_micro_batches_equal_one_batch():
     """Splitting the batch (what data parallelism and large-B runs do) leaves loss and grads unchanged."""
     tl, T, B, H, Z, K, learn_std, miss, _ = CASES["aligned_h32"]
