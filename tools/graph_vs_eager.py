@@ -54,8 +54,6 @@ for it in range(steps):
             probe.set_noise(lu, le)
             l2 = probe(x, mask, beta=1.0, temp=3.0)
             print("  eager step, same parameters and noise tensors: %s" % {k: float(v.detach()) for k, v in l2.items()})
-            for name in ("z", "z_std", "s", "dec_params"):
-                pass
         o.step()
         vals.append((v0, gn))
     dp = float((models[0].flat_params - models[1].flat_params).abs().max())
