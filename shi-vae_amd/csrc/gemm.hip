@@ -919,8 +919,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumParams p) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
     const int r0 = blockIdx.z * p.rows_per_block, r1 = min(p.M, r0 + p.rows_per_block);
     float s = 0.f;
-    if (c < p.N)
-        for (int r = r0 + ry; r < r1; r += 4) s += g.Y[(size_t)r * p.ld + c];
+    if (c < p.N) {
+        // (four independent partial sums: the loads of a block are then requested four deep instead of one by one)
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {
+            s += g.Y[(size_t)r * p.ld + c];
+            s1 += g.Y[(size_t)(r + 4) * p.ld + c];
+            s2 += g.Y[(size_t)(r + 8) * p.ld + c];
+            s3 += g.Y[(size_t)(r + 12) * p.ld + c];
+        }
+        for (; r < r1; r += 4) s += g.Y[(size_t)r * p.ld + c];
+        s += s1 + s2 + s3;
+    }
     part[ry][threadIdx.x & 63] = s;
     __syncthreads();
     if (ry == 0 && c < p.N) atomicAdd(g.out + c, part[0][threadIdx.x] + part[1][threadIdx.x] +
@@ -933,9 +944,10 @@ int launch_colsum(int M, int N, int ld, const ColsumGroup* groups_dev, int ngrou
     SV_REQUIRE(groups_dev != nullptr || ngroups == 1, "colsum: groups need a device table");
     ColsumParams p;
     p.M = M; p.N = N; p.ld = ld;
-    // enough blocks to fill the chip, at least 256 rows each
+    // enough blocks to fill the chip, at least 256 rows each -- 64 for a matrix of a few thousand rows, whose launch
+    // is a latency chain of one block's row loop (cfg2: 21 launches of 15 us per step with 256-row blocks)
     int zs = ceil_div(2048, ceil_div(N, 64) * ngroups);
-    zs = std::max(1, std::min(zs, ceil_div(M, 256)));
+    zs = std::max(1, std::min(zs, ceil_div(M, M <= 65536 ? 64 : 256)));
     p.rows_per_block = ceil_div(M, zs);
     zs = ceil_div(M, p.rows_per_block);
     p.groups = groups_dev; p.g0 = g0;

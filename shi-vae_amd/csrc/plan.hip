@@ -598,6 +598,49 @@ static int zero_async(float* buf, size_t floats, hipStream_t s) {
 
 constexpr int64_t FANOUT_MAX_ROWS = 65536;  // steps of at most this many (t, b) rows fan their independent launches out (shivae_plan::side)
 
+// Fork / join of a small step's stream with the plan's side streams (shivae_plan::side): side() hands out a side stream
+// (forking on first use: the side streams wait for everything issued on `s` so far), join() makes `s` wait for all of
+// them.  Launches given to a side stream must not be read by anything issued on `s` before the next join.
+struct Fan {
+    shivae_plan* p;
+    hipStream_t s;
+    bool on, forked = false;
+    int turn = 0;
+    Fan(shivae_plan* plan, hipStream_t stream) : p(plan), s(stream) {
+        static const bool fan_on = [] { const char* f = getenv("SHIVAE_FANOUT"); return !f || atoi(f) != 0; }();
+        on = fan_on && p->side[0] && p->R <= FANOUT_MAX_ROWS && !prof_on();
+    }
+    hipStream_t side() {
+        if (!on) return s;
+        if (!forked) {
+            if (hipEventRecord(p->ev_fork, s) != hipSuccess) { on = false; return s; }
+            for (int i = 0; i < shivae_plan::NSIDE; ++i)
+                if (hipStreamWaitEvent(p->side[i], p->ev_fork, 0) != hipSuccess) { on = false; return s; }
+            forked = true;
+        }
+        const int i = turn;
+        turn = (turn + 1) % shivae_plan::NSIDE;
+        return p->side[i];
+    }
+    // the side streams also wait for what has been issued on `s` since the fork
+    void sync_sides() {
+        if (!on) return;
+        forked = false;
+        turn = 0;
+        (void)side();
+        turn = 0;
+    }
+    int join() {
+        if (!forked) return SHIVAE_OK;
+        forked = false;
+        for (int i = 0; i < shivae_plan::NSIDE; ++i) {
+            SV_CHECK_HIP(hipEventRecord(p->ev_join[i], p->side[i]));
+            SV_CHECK_HIP(hipStreamWaitEvent(s, p->ev_join[i], 0));
+        }
+        return SHIVAE_OK;
+    }
+};
+
 // ------------------------------------------------------------ GEMM helpers
 static int splitk_for(int M, int N, int K, int groups) {
     const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * groups;
@@ -605,7 +648,9 @@ static int splitk_for(int M, int N, int K, int groups) {
     // K chunk per workgroup: long enough to amortise the tile's prologue and atomic epilogue when there are many
     // tiles; with a handful of tiles (small models: one 256x32 tile per weight gradient) the launch is a latency
     // chain of K-tiles in a few workgroups, so shorter chunks on more CUs win (cfg1: 43 -> 14 us per launch)
-    const int min_chunk = tiles <= 4 ? 128 : (tiles <= 32 ? 256 : 512);
+    // (64: cfg1 2.53 -> 2.49 ms/step, cfg2 2.10 -> 2.04 against 128; 32 is no faster)
+    static const int tiny_chunk = [] { const char* f = getenv("SHIVAE_TN_MINCHUNK"); return f && atoi(f) >= 32 ? atoi(f) : 64; }();
+    const int min_chunk = tiles <= 4 ? tiny_chunk : (tiles <= 32 ? 256 : 512);
     sk = std::min(sk, ceil_div(K, min_chunk));
     sk = std::min(sk, 65535 / std::max(groups, 1));
     return std::max(sk, 1);
@@ -786,6 +831,7 @@ static int phase_prior_kl(shivae_plan* p, float beta, float inv_batch, bool grad
     const int NT = GEMM_NT, NN = GEMM_NN, TN = GEMM_TN;
     float *emb = p->wsf("emb"), *d_emb = p->wsf("d_emb"), *rowloss = p->wsf("rowloss");
     if (grad) SV_TRY(zero_async(d_emb, (size_t)R * Ep, s));
+    Fan fan(p, s);
 
     const float *Wp0 = p->prm(g[SHIVAE_P_PRIOR0_W]), *Wpm = p->prm(g[SHIVAE_P_PRIORMEAN_W]),
                 *Wps = p->prm(g[SHIVAE_P_PRIORSTD_W]);
@@ -819,23 +865,27 @@ static int phase_prior_kl(shivae_plan* p, float beta, float inv_batch, bool grad
                              rowloss + (size_t)r0 * 6, s));
             prof_end(s);
             if (!grad) continue;
+            // Small steps (Fan): the weight / bias gradients only read what is already there and go to the side streams;
+            // the step's stream carries the chain dmu, dsd -> dprc -> d_emb.
+            SV_TRY(gemm1(TN, Z, H, rb, dmupc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, fan.side()));
+            SV_TRY(gemm1(TN, Z, H, rb, dsdpc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, fan.side()));
+            SV_TRY(colsum1(rb, Z, Zp, dmupc, p->grd(g[SHIVAE_P_PRIORMEAN_B]), fan.side()));
+            SV_TRY(colsum1(rb, Z, Zp, dsdpc, p->grd(g[SHIVAE_P_PRIORSTD_B]), fan.side()));
             SV_TRY(gemm1(NN, rb, H, Z, dmupc, Zp, Wpm, H, dprc, Hp, nullptr, nullptr, 0, 0, s));
             SV_TRY(gemm1(NN, rb, H, Z, dsdpc, Zp, Wps, H, dprc, Hp, nullptr, prc, Hp, EPI_ADDC | EPI_MASK, s));
-            SV_TRY(gemm1(TN, Z, H, rb, dmupc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORMEAN_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-            SV_TRY(gemm1(TN, Z, H, rb, dsdpc, Zp, prc, Hp, p->grd(g[SHIVAE_P_PRIORSTD_W]), H, nullptr, nullptr, 0, EPI_ATOMIC, s));
-            SV_TRY(colsum1(rb, Z, Zp, dmupc, p->grd(g[SHIVAE_P_PRIORMEAN_B]), s));
-            SV_TRY(colsum1(rb, Z, Zp, dsdpc, p->grd(g[SHIVAE_P_PRIORSTD_B]), s));
+            fan.sync_sides();  // (dprc is ready for them, too)
             float* gWp0 = p->grd(g[SHIVAE_P_PRIOR0_W]);
-            SV_TRY(gemm1(TN, H, H, rb, dprc, Hp, emb_h, Ep, gWp0, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
-            SV_TRY(gemm1(TN, H, K, rb, dprc, Hp, emb_s, Ep, gWp0 + H, H + K, nullptr, nullptr, 0, EPI_ATOMIC, s));
-            SV_TRY(colsum1(rb, H, Hp, dprc, p->grd(g[SHIVAE_P_PRIOR0_B]), s));
+            SV_TRY(gemm1(TN, H, H, rb, dprc, Hp, emb_h, Ep, gWp0, H + K, nullptr, nullptr, 0, EPI_ATOMIC, fan.side()));
+            SV_TRY(gemm1(TN, H, K, rb, dprc, Hp, emb_s, Ep, gWp0 + H, H + K, nullptr, nullptr, 0, EPI_ATOMIC, fan.side()));
+            SV_TRY(colsum1(rb, H, Hp, dprc, p->grd(g[SHIVAE_P_PRIOR0_B]), fan.side()));
             // into the (zeroed) d_emb records; the decoder chunks add their part below
             float* de = d_emb + (size_t)r0 * Ep;
             SV_TRY(gemm1(NN, rb, H, H, dprc, Hp, Wp0, H + K, de + Hp + Kp, Ep, nullptr, nullptr, 0, 0, s));
             SV_TRY(gemm1(NN, rb, K, H, dprc, Hp, Wp0 + H, H + K, de + Hp, Ep, nullptr, nullptr, 0, 0, s));
         }
     }
-
+    // (the side launches read scratch borrowed from records that the reverse scan writes: done before the phase ends)
+    SV_TRY(fan.join());
     return SHIVAE_OK;
 }
 
@@ -968,11 +1018,16 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(gemmg(NN, rr, H, nout, P, H, ldin, ldin, EPI_MASK | EPI_COLSUM, p->b_out_d[key], s,
                          rag ? RAG_CNT | RAG_AIDX : 0));
         }
-        SV_TRY(gemmg(TN, H, H, rr, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, s, rcnt));
+        // (small steps, Fan: a layer's weight gradient reads what the chain has produced so far and nothing reads it --
+        // it goes to a side stream while the step's stream carries the input gradients dhh -> da2 -> da1 -> da0)
+        Fan fan(p, s);
+        SV_TRY(gemmg(TN, H, H, rr, ldHH, ldA1, H, 0, EPI_ATOMIC, p->b_h0_w, fan.side(), rcnt));
         SV_TRY(gemmg(NT, rr, H, H, ldHH, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_h0_d, s, rcnt));
-        SV_TRY(gemmg(TN, H, H, rr, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, s, rcnt));
+        fan.sync_sides();
+        SV_TRY(gemmg(TN, H, H, rr, ldA1, ldA1, H, 0, EPI_ATOMIC, p->b_l2_w, fan.side(), rcnt));
         SV_TRY(gemmg(NT, rr, H, H, ldA1, H, ldA1, ldA1, EPI_MASK | EPI_COLSUM, p->b_l2_d, s, rcnt));
-        SV_TRY(gemmg(TN, H, 2 * H, rr, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, s, rcnt));
+        fan.sync_sides();
+        SV_TRY(gemmg(TN, H, 2 * H, rr, ldA1, ldA0, 2 * H, 0, EPI_ATOMIC, p->b_l1_w, fan.side(), rcnt));
         // Layer 0 backward, input gradient (the sum over attributes of decoders.py:127's shared input) in two forms.
         // "compact": da0 stays compact like the activations and one grouped GEMM over the observed rows of every
         // attribute ADDS its tiles into the chunk's rows: flops follow the observed fraction f, but every product is
@@ -998,6 +1053,7 @@ static int phase_decoder(shivae_plan* p, const float* x, const uint8_t* mask, fl
             SV_TRY(gemm1(TN, D * 2 * H, E, rc, da0, ldA0, embc, E4, p->grd(g[SHIVAE_P_DEC0_W]), E, nullptr, nullptr, 0,
                          EPI_ATOMIC, s));
         }
+        SV_TRY(fan.join());  // (what follows overwrites the layer-1/2 buffers, or belongs to the next chunk)
         if (cd && p->l0_prod && p->l0_gather) {
             // Compact form without atomics: each attribute's product rows are stored where the dead layer-1/2 buffers
             // were (plain stores), then one pass sums, per chunk row, the rows of the attributes observed in it.
