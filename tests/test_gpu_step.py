@@ -390,6 +390,38 @@ def test_captured_training_run_matches_eager_stepwise():
         opt.step()
 
 
+def test_captured_step_with_fills_inside_gemms_matches_oracle():
+    """A captured step whose GEMM helper zero-fills inside the step (K = D*2H = 8192: the layer-0 input gradient splits
+    K and adds atomically into cleared columns, main launch and the 16-column remainder of E = 528 alike): under capture
+    those fills are store kernels (plan.hip zero2d_async).  Eager call, capture + replay, replay -- each against the oracle."""
+    tl = shivae_amd.utils.make_types_list(4, 4, 4, [3] * 4, interleave=True)
+    T, B, H, Z, K = 3, 24, 256, 64, 16
+    rng = np.random.default_rng(2024)
+    P = so.init_params(tl, H, Z, K, True, seed=3)
+    x, mask = _synth(rng, tl, T, B, 0.3)
+    u = rng.random((T, B, K)).astype(np.float32)
+    eps = rng.standard_normal((T, B, Z)).astype(np.float32)
+    om = so.OracleShiVAE(P, tl, H, Z, K, True)
+    c = om.forward(x, mask, u, eps, 0.8, 1.5)
+    if _golden.dekink_decoder(P, tl, c["emb"]):
+        om = so.OracleShiVAE(P, tl, H, Z, K, True)
+        c = om.forward(x, mask, u, eps, 0.8, 1.5)
+    G = om.backward()
+    m = shivae_amd.ShiVAE(H, Z, K, 1, types_list=tl, learn_std=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m.train()
+    for call in range(3):
+        m.zero_grad()
+        m.set_noise(u, eps)
+        loss = m(torch.from_numpy(x), torch.from_numpy(mask), beta=0.8, temp=1.5)
+        loss["n_elbo"].backward()
+        assert len(m._graphs) == (1 if call else 0)
+        for k in shivae_amd.LOSS_KEYS:
+            np.testing.assert_allclose(float(loss[k].detach()), c["losses"][k], rtol=LOSS_RTOL, atol=1e-5, err_msg="%s call %d" % (k, call))
+        bad = _golden.bad_grads(_grads(m), G)
+        assert not bad, (call, bad[:8])
+
+
 def test_micro_batches_equal_one_batch():
     """Splitting the batch (what data parallelism and large-B runs do) leaves loss and grads unchanged."""
     tl, T, B, H, Z, K, learn_std, miss, _ = CASES["aligned_h32"]
