@@ -596,7 +596,12 @@ static int zero_async(float* buf, size_t floats, hipStream_t s) {
     return SHIVAE_OK;
 }
 
-constexpr int64_t FANOUT_MAX_ROWS = 65536;  // steps of at most this many (t, b) rows fan their independent launches out (shivae_plan::side)
+// steps of at most this many (t, b) rows fan their independent launches out (shivae_plan::side); SHIVAE_FANOUT_ROWS
+static int64_t fanout_max_rows() {
+    static const int64_t v = [] { const char* f = getenv("SHIVAE_FANOUT_ROWS"); return f ? atoll(f) : (int64_t)65536; }();
+    return v;
+}
+#define FANOUT_MAX_ROWS fanout_max_rows()
 
 // Fork / join of a small step's stream with the plan's side streams (shivae_plan::side): side() hands out a side stream
 // (forking on first use: the side streams wait for everything issued on `s` so far), join() makes `s` wait for all of
