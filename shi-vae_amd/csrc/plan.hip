@@ -601,7 +601,6 @@ static int64_t fanout_max_rows() {
     static const int64_t v = [] { const char* f = getenv("SHIVAE_FANOUT_ROWS"); return f ? atoll(f) : (int64_t)65536; }();
     return v;
 }
-#define FANOUT_MAX_ROWS fanout_max_rows()
 
 // Fork / join of a small step's stream with the plan's side streams (shivae_plan::side): side() hands out a side stream
 // (forking on first use: the side streams wait for everything issued on `s` so far), join() makes `s` wait for all of
@@ -613,7 +612,7 @@ struct Fan {
     int turn = 0;
     Fan(shivae_plan* plan, hipStream_t stream) : p(plan), s(stream) {
         static const bool fan_on = [] { const char* f = getenv("SHIVAE_FANOUT"); return !f || atoi(f) != 0; }();
-        on = fan_on && p->side[0] && p->R <= FANOUT_MAX_ROWS && !prof_on();
+        on = fan_on && p->side[0] && p->R <= fanout_max_rows() && !prof_on();
     }
     hipStream_t side() {
         if (!on) return s;
@@ -1139,7 +1138,7 @@ static int phase_scan_bwd(shivae_plan* p, const float* x, const float* u, const 
         //    here to the end of the phase only reads the records and writes a gradient tensor of its own (the phi_x
         //    chain excepted, which stays on one stream): small steps deal them round the side streams.
         static const bool fan_on = [] { const char* f = getenv("SHIVAE_FANOUT"); return !f || atoi(f) != 0; }();
-        const bool fan = fan_on && p->side[0] && p->R <= FANOUT_MAX_ROWS && !prof_on();
+        const bool fan = fan_on && p->side[0] && p->R <= fanout_max_rows() && !prof_on();
         int turn = 0;
         auto S = [&]() -> hipStream_t {
             if (!fan) return s;
@@ -1438,7 +1437,7 @@ int shivae_plan_bind(shivae_plan* p, void* ws, size_t bytes, float* params, floa
         p->cnt_next = 0;
         SV_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->cnt_guard), (size_t)p->D * sizeof(int), hipHostMallocDefault));
     }
-    if (p->R <= FANOUT_MAX_ROWS) {  // (only steps small enough to use them get side streams)
+    if (p->R <= fanout_max_rows()) {  // (only steps small enough to use them get side streams)
         SV_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < shivae_plan::NSIDE; ++i) {
             SV_CHECK_HIP(hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking));
